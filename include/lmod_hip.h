@@ -1,0 +1,145 @@
+/* lmod_hip.h — C ABI of the MI355X (gfx950) kernels behind the LLaVA-MoD distillation step.
+ *
+ * The reference (shufangxun/LLaVA-MoD) is pure Python and has NO native interface of its own:
+ * every op below is what the reference reaches through torch / HF transformers / DeepSpeed at the
+ * cited call site.  This header is therefore the boundary a maintainer binds with ctypes
+ * (see INTEGRATION.md); nothing in it carries a torch type.
+ *
+ * Conventions: raw device pointers, explicit dims / leading dimensions (in ELEMENTS), the HIP
+ * stream to enqueue on, caller-owned outputs and workspaces.  Every function only enqueues work
+ * (no allocation, no synchronisation) and returns 0 on success or a negative LMOD_E* code; it
+ * never throws.  bf16 tensors are `void*` to raw uint16 bit patterns.  No global mutable state.
+ */
+#ifndef LMOD_HIP_H
+#define LMOD_HIP_H
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMOD_OK 0
+#define LMOD_EINVAL (-1)       /* bad pointer / shape / alignment */
+#define LMOD_ELAUNCH (-2)      /* HIP reported a launch error */
+#define LMOD_EUNSUPPORTED (-3) /* valid request outside the compiled envelope */
+
+/* ---- GEMM ------------------------------------------------------------------------------------
+ * C[b] (+)= act(A[b] (M x K, row-major, lda) * B[b]^T (N x K, row-major, ldb) + bias[N]).
+ * Replaces nn.Linear forward: qwen2/modeling_qwen2.py:262-264,320 (QKV/O), :186-187 (SwiGLU MLP),
+ * :1163 (lm_head); multimodal_projector/builder.py:57-61; HF CLIP linears + patch conv
+ * (multimodal_encoder/clip_encoder.py:54).  With m_valid/k_valid (device int[batch]) it is the
+ * grouped GEMM over DeepSpeed MoE capacity slabs (deepspeed.moe.experts; llava_qwen2_moe.py:536-546).
+ * act: 0 none, 1 exact GELU, 2 quick_gelu.  out_f32: C is fp32.  accumulate: C += .
+ * Requires K % 8 == 0, lda/ldb % 8 == 0, A/B 16-byte aligned. */
+int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
+                      int ldc, int batch, long long strideA, long long strideB, long long strideC, const int* m_valid,
+                      const int* k_valid, int act, int out_f32, int accumulate, hipStream_t stream);
+
+/* out[C x ld_out] = in[R x C]^T, zero-filling columns R..ld_out-1 (makes dgrad / wgrad operands
+ * K-contiguous for lmod_gemm_bf16_nt; autograd's implicit .t() in the reference). */
+int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int ld_out, int batch,
+                        long long stride_in, long long stride_out, hipStream_t stream);
+
+/* ---- row kernels -----------------------------------------------------------------------------
+ * Qwen2RMSNorm (qwen2/modeling_qwen2.py:83-97) with the decoder layer's residual add fused
+ * (:757-775, llava_qwen2_moe.py:143-167): h = res ? bf16(x+res) : x; y = w * bf16(h*rstd).
+ * res, h_out, rstd may be NULL. */
+int lmod_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd, int T, int H,
+                     float eps, hipStream_t stream);
+/* dh = rmsnorm_bwd(dy; h, w, rstd) + dres (dres may be NULL).  Norm weights are frozen in every
+ * stage of the reference (llava_qwen2_moe.py:501-506), so no dw. */
+int lmod_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dh,
+                     int T, int H, hipStream_t stream);
+/* nn.LayerNorm forward of the frozen CLIP tower (clip_encoder.py:45 runs under no_grad). */
+int lmod_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int T, int H, float eps,
+                       hipStream_t stream);
+/* apply_rotary_pos_emb (qwen2/modeling_qwen2.py:146-171), in place on the first `nheads` heads
+ * of each row of buf[T x ld]; cos/sin: [max_pos x hd] bf16; pos: int32[T]; backward != 0 applies
+ * the gradient map. */
+int lmod_rope(void* buf, const void* cos_t, const void* sin_t, const int* pos, int T, int nheads, int hd, int ld,
+              int backward, hipStream_t stream);
+/* Qwen2MLP activation (qwen2/modeling_qwen2.py:186-187): out = bf16(silu(gate)) * up. */
+int lmod_swiglu_fwd(const void* gate, const void* up, void* out, long long rows, int I, int ld_gate, int ld_up,
+                    int ld_out, hipStream_t stream);
+int lmod_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, long long rows, int I,
+                    int ld_dact, int ld_gate, int ld_up, int ld_dgate, int ld_dup, hipStream_t stream);
+/* nn.GELU() of the mlp2x_gelu projector (multimodal_projector/builder.py:57-61). */
+int lmod_gelu_fwd(const void* x, void* y, long long n, hipStream_t stream);
+int lmod_gelu_bwd(const void* dy, const void* x, void* dx, long long n, hipStream_t stream);
+int lmod_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream);
+/* out[r] = idx[r] >= 0 ? srcA[idx[r]] : idx[r] <= -2 ? srcB[-(idx[r]+2)] : 0.  Embedding lookup +
+ * image-feature splice of prepare_inputs_labels_for_multimodal (llava_arch.py:236-318), the MoE
+ * dispatch (einsum 'sec,sm->ecm' of deepspeed MOELayer.forward), and their backward gathers. */
+int lmod_gather_rows(const void* srcA, const void* srcB, const int* idx, void* out, long long rows, int H,
+                     hipStream_t stream);
+/* CLIP patch embedding front end (HF CLIPVisionEmbeddings; call site clip_encoder.py:54). */
+int lmod_im2col_patch(const void* pixels, void* out, int B, int image_size, int patch, int Kpad, hipStream_t stream);
+int lmod_vit_embed(const void* patch_emb, const void* cls, const void* pos, void* out, int B, int n_patches, int D,
+                   hipStream_t stream);
+/* torch.optim.AdamW step (HF `adamw_torch`, config/args.py:78) on fp32 master weights with a bf16
+ * working copy; grad is fp32, scaled by grad_scale first. */
+int lmod_adamw_step(float* master, void* param_bf16, const float* grad, float* m, float* v, long long n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    hipStream_t stream);
+
+/* ---- attention -------------------------------------------------------------------------------
+ * softmax(Q K^T * scale + mask) V with causal and right-padding masks, GQA (nh % nkv == 0).
+ * Replaces F.scaled_dot_product_attention / flash_attn (qwen2/modeling_qwen2.py:700-708,535-581)
+ * and CLIP encoder attention.  hd in {64, 128}.  lse: [B, nh, S] fp32 (may be NULL in fwd). */
+int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens, int B, int S,
+                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
+                  hipStream_t stream);
+int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, int B, int S, int nh, int nkv,
+                  int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
+                  int causal, hipStream_t stream);
+
+/* ---- sparse MoE (DeepSpeed 0.9.5 TopKGate/top1gating/top2gating/MOELayer semantics) ------------
+ * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32). */
+int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);
+/* top-k (k in {1,2}) gating with capacity C: token-order slot assignment, drops, renormalised
+ * combine weights, l_aux, exp_counts.  noise: additive [T,E] noise for the 2nd choice or NULL. */
+int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
+                  int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
+                  int* exp_counts, float* gate_sum, float* l_aux, int* scratch, hipStream_t stream);
+/* out[t] = bf16(w1)*y[slot1[t]] + bf16(w2)*y[slot2[t]]   (einsum 'sec,ecm->sm'). */
+int lmod_moe_combine_fwd(const void* y, const int* slot1, const int* slot2, const float* w1, const float* w2,
+                         void* out, int T, int H, hipStream_t stream);
+int lmod_moe_combine_bwd(const void* dout, const void* y, const int* slot1, const int* slot2, const int* slot_token,
+                         const float* slot_w, void* dy, float* dw1, float* dw2, int T, int S, int H,
+                         hipStream_t stream);
+int lmod_moe_gate_bwd(const float* gates, const int* idx1, const int* idx2, const int* slot1, const int* slot2,
+                      const float* dw1, const float* dw2, const int* exp_counts, const float* d_laux, float* dlogits,
+                      int T, int E, int k, hipStream_t stream);
+int lmod_moe_dispatch_bwd(const void* d_in, const int* slot1, const int* slot2, const float* dlogits, const float* wg,
+                          void* dx, int T, int H, int E, hipStream_t stream);
+int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float* workspace, int T, int H, int E,
+                          int accumulate, hipStream_t stream);
+
+/* ---- distillation losses -----------------------------------------------------------------------
+ * One pass per logits row.  stats[R][8] = {lse_s_full, lse_s_align, lse_t_align, x_kd, ce, s[label],
+ * finite_mass, 0}:  x_kd = sum_v softmax(t[:Va])_v * log_softmax(s[:Va])_v with the isinf mask
+ * (AlignTrainer.get_p/get_logp/compute_align_loss, align_trainer.py:455-528);  ce = lse_full - s[label]
+ * (CrossEntropyLoss of llava_qwen2_moe.py:407-421; DPOTrainer.get_logp per-token logp = -ce,
+ * dpo_trainer.py:483-495).  t may be NULL (no teacher row). */
+int lmod_rowloss_fwd(const void* s, long long ld_s, int Vs, const void* t, long long ld_t, int Va, const int* label,
+                     float* stats, int R, hipStream_t stream);
+/* ds = kd_w[r]*kd_scale[seg]*(softmax_a(s)-softmax_a(t))[v<Va] + ce_w[r]*ce_scale[seg]*(softmax(s)-onehot). */
+int lmod_rowloss_bwd(const void* s, long long ld_s, int Vs, const void* t, long long ld_t, int Va, const int* label,
+                     const float* stats, const float* kd_w, const float* ce_w, const int* seg_id,
+                     const float* kd_scale, const float* ce_scale, void* ds, long long ld_ds, int R,
+                     hipStream_t stream);
+/* out_sum[b] = sum_{r in [seg_off[b], seg_off[b+1])} w[r]*val[r*stride+col]; out_w[b] = sum w[r]. */
+int lmod_segment_wsum(const float* val, int stride, int col, const float* w, const int* seg_off, int nseg,
+                      float* out_sum, float* out_w, hipStream_t stream);
+/* DPOTrainer.dpo_loss (dpo_trainer.py:497-562), forward + d(mean loss)/d(policy logps).
+ * loss_type: 0 sigmoid, 1 hinge, 2 ipo, 3 kto_pair (losses has 2B entries). */
+int lmod_dpo_loss(const float* policy_chosen, const float* policy_rejected, const float* ref_chosen,
+                  const float* ref_rejected, int B, float beta, float label_smoothing, int loss_type, float* losses,
+                  float* chosen_rewards, float* rejected_rewards, float* d_policy_chosen, float* d_policy_rejected,
+                  hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMOD_HIP_H */

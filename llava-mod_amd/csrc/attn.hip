@@ -1,0 +1,586 @@
+// Flash-style attention for gfx950, forward + backward, bf16 in / fp32 accumulate.
+// Replaces F.scaled_dot_product_attention / flash_attn_func / the eager path of the reference
+// decoder (qwen2/modeling_qwen2.py:700-708, :535-581, :290-309) and HF CLIP's encoder attention
+// (call site multimodal_encoder/clip_encoder.py:54).  Causal + right-padding key mask
+// (keys >= seqlens[b] are masked, like the 4-D mask of :1019-1027); GQA via `group`.
+//
+// Lane algebra (MFMA 16x16x32; first/second operand share one register layout:
+// index = lane&15, reduction slots = (lane>>4)*8 + j; D[row=(lane>>4)*4+r][col=lane&15]):
+//   S^T tile = mfma(first = K rows, second = Q rows)  -> lane holds 4 keys x ONE query (lane&15)
+//   => row max / row sum are in-lane + two xor-shuffles; alpha, m, l are lane-local.
+//   The reduction-slot order of an MFMA is free as long as both operands agree, so the S^T
+//   accumulators ARE the second operand of the next MFMA (slot j<4 <- key tile 2s, j>=4 <- tile
+//   2s+1): O^T = mfma(first = V^T rows (d), second = P) with V^T read from LDS in the same slot
+//   order.  No LDS round trip, no cross-lane movement for P / dS.
+//   V^T (and K^T, Q^T, dO^T in backward) are built by transposing through registers while
+//   staging; their d-rows are permuted (rho) so each lane ends up with 16 contiguous d values
+//   of one token row -> 16-byte epilogue stores.
+// K / V / Q / dO row-major tiles go global->LDS by LDS-DMA with the XOR swizzle applied on the
+// source address (LDS-DMA writes lane-linear) and on the ds_read side.
+#include "common.h"
+
+#define ATT_OOB 0x80000000u
+#define TP 136   // byte pitch of a transposed-tile row (64 tokens * 2 B + 8 B pad): conflict-free b64 reads
+
+struct AttnP {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
+  const bf16_t* dO; const float* Delta; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+  const int* seqlens;
+  int B, S, nh, group;           // group = nh / nkv
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  float scale;
+};
+
+__device__ __forceinline__ int rho_row(int d) {   // d (0..HD-1) -> row of the transposed LDS image
+  const int dl = d & 63;
+  return (d & ~63) + (((dl >> 2) & 3) << 4) + ((dl >> 4) << 2) + (dl & 3);
+}
+
+// Stage a [64 x HD] row-major bf16 tile into LDS by LDS-DMA (swizzled).  rs covers the whole
+// [S x ld] matrix of this (batch, head); rows >= S read as zeros.
+template <int HD>
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int wave, int lane, int row0,
+                                           int S, int ld) {
+  constexpr int NC = HD / 8, RPW = 1024 / (HD * 2), LPW = 64 / RPW / 4;
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int wl = wave * LPW + j;
+    const int row = wl * RPW + lane / NC;
+    const int ch = (lane % NC) ^ (row & (NC - 1));
+    const uint32_t vo = (row0 + row < S) ? (uint32_t)(row * ld * 2 + ch * 16) : ATT_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + wl * 1024), 16, vo, row0 * ld * 2, 0, 0);
+  }
+}
+
+// Read one MFMA operand (8 bf16 of row `row`, logical chunk `chunk`) from a stage_rows image.
+template <int HD>
+__device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk) {
+  constexpr int NC = HD / 8;
+  return *(const bf16x8*)(tile + row * (HD * 2) + ((chunk ^ (row & (NC - 1))) << 4));
+}
+
+// Stage the TRANSPOSE of a [64 x HD] tile: T[rho(d)][token] (pitch TP bytes), through registers.
+template <int HD>
+__device__ __forceinline__ void stage_transposed(const bf16_t* base /* row0 of tile, head column 0 */, int ld,
+                                                 int rows_valid, char* tT, int tid) {
+  constexpr int NC = HD / 8, KPT = HD / 32;
+  const int dch = tid % NC, t0 = (tid / NC) * KPT;
+  u32x4 vr[KPT];
+#pragma unroll
+  for (int a = 0; a < KPT; ++a) {
+    if (t0 + a < rows_valid) vr[a] = *(const u32x4*)(base + (long long)(t0 + a) * ld + dch * 8);
+    else vr[a] = (u32x4){0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) {
+    const int r = rho_row(dch * 8 + dd);
+    uint32_t e[KPT];
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) { const uint32_t w = vr[a][dd >> 1]; e[a] = (dd & 1) ? (w >> 16) : (w & 0xffffu); }
+    if constexpr (KPT == 4) {
+      u32x2 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+      *(u32x2*)(tT + r * TP + t0 * 2) = o;
+    } else {
+      *(uint32_t*)(tT + r * TP + t0 * 2) = e[0] | (e[1] << 16);
+    }
+  }
+}
+
+// Operand from a transposed image for reduction step st (32 tokens): slots j<4 = tokens
+// 32st + g*4 + j, slots j>=4 = tokens 32st + 16 + g*4 + (j-4).
+__device__ __forceinline__ bf16x8 read_transposed(const char* tT, int dtile, int st, int li, int g) {
+  const char* p = tT + ((dtile >> 2) * 64 + (dtile & 3) * 16 + li) * TP + (st * 32 + g * 4) * 2;
+  const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 32);
+  u32x4 r = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
+  u32x4 r = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ float xmax16(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xsum16(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// ============================================================================ forward
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+  constexpr int KS = HD / 32, DT = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                 // 64 x HD bf16, swizzled
+  char* sVt = smem + 64 * HD * 2;  // HD rows x TP
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy blocks first
+  const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
+  const int S = p.S;
+  const int len = p.seqlens ? min(p.seqlens[b], S) : S;
+  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const long long tok0 = (long long)b * S;
+
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = qw0 + qt * 16 + li;
+      if (q < S) qf[qt][ks] = *(const bf16x8*)(p.Q + (tok0 + q) * p.ldq + h * HD + ks * 32 + g * 8);
+      else qf[qt][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  f32x4 o[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[qt][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+  const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
+  const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
+  const float c = p.scale * 1.4426950408889634f;
+  const int kv_end = CAUSAL ? min(q0 + 128, len) : len;
+  const int ntiles = (kv_end + 63) >> 6;
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int kv0 = j * 64;
+    __syncthreads();
+    stage_rows<HD>(rsK, sK, wave, lane, kv0, S, p.ldk);
+    stage_transposed<HD>(Vb + (long long)kv0 * p.ldv, p.ldv, S - kv0, sVt, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (CAUSAL && kv0 > qw0 + 31) continue;      // wave-uniform: nothing visible to this wave
+
+    f32x4 s[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) s[qt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bf16x8 kf = read_rows<HD>(sK, nt * 16 + li, ks * 4 + g);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][nt], 0, 0, 0);
+      }
+    const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qw0 + qt * 16 + li;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[qt][nt][r] * c;
+          if (need_mask) {
+            const int key = kv0 + nt * 16 + g * 4 + r;
+            if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
+          }
+          s[qt][nt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = xmax16(mx);
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[qt][nt][r] - msafe);
+          s[qt][nt][r] = pv;
+          rs += pv;
+        }
+      rs = xsum16(rs);
+      lrun[qt] = lrun[qt] * alpha + rs;
+      mrun[qt] = mnew;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
+      pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
+      pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16x8 vf = read_transposed(sVt, d, st, li, g);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qw0 + qt * 16 + li;
+    if (q >= S) continue;
+    const float inv = lrun[qt] > 0.f ? 1.f / lrun[qt] : 0.f;
+    bf16_t* op = p.O + (tok0 + q) * p.ldo + h * HD + g * 16;
+#pragma unroll
+    for (int sp = 0; sp < HD / 64; ++sp) {
+      u32x4 w0, w1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        w0[k * 2] = pack2bf(o[qt][sp * 4 + k][0] * inv, o[qt][sp * 4 + k][1] * inv);
+        w0[k * 2 + 1] = pack2bf(o[qt][sp * 4 + k][2] * inv, o[qt][sp * 4 + k][3] * inv);
+        w1[k * 2] = pack2bf(o[qt][sp * 4 + 2 + k][0] * inv, o[qt][sp * 4 + 2 + k][1] * inv);
+        w1[k * 2 + 1] = pack2bf(o[qt][sp * 4 + 2 + k][2] * inv, o[qt][sp * 4 + 2 + k][3] * inv);
+      }
+      *(u32x4*)(op + sp * 64) = w0;
+      *(u32x4*)(op + sp * 64 + 8) = w1;
+    }
+    if (g == 0 && p.LSE)
+      p.LSE[((long long)b * p.nh + h) * S + q] =
+          (lrun[qt] > 0.f) ? (mrun[qt] + __builtin_amdgcn_logf(lrun[qt])) * 0.6931471805599453f : -INFINITY;
+  }
+}
+
+// ============================================================================ backward: delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                        float* __restrict__ delta, int B, int S, int nh, int HD,
+                                                        int lddo, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, s, h)
+  const long long total = (long long)B * S * nh;
+  if (id >= total) return;
+  const int h = (int)(id % nh);
+  const long long tok = id / nh;
+  const int b = (int)(tok / S), s = (int)(tok % S);
+  float a = 0.f;
+  for (int cidx = lane; cidx < (HD >> 3); cidx += 64) {
+    const u32x4 x = *(const u32x4*)(dO + tok * lddo + h * HD + cidx * 8);
+    const u32x4 y = *(const u32x4*)(O + tok * ldo + h * HD + cidx * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a += bflo(x[k]) * bflo(y[k]) + bfhi(x[k]) * bfhi(y[k]);
+  }
+  a = wave_sum(a);
+  if (lane == 0) delta[((long long)b * nh + h) * S + s] = a;
+}
+
+// ============================================================================ backward: dQ
+// One block = 128 queries of one (b, head); loops over K/V tiles of 64 keys (same range as forward).
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+  constexpr int KS = HD / 32, DT = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 64 * HD * 2;
+  char* sKt = smem + 2 * 64 * HD * 2;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
+  const int S = p.S;
+  const int len = p.seqlens ? min(p.seqlens[b], S) : S;
+  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const long long tok0 = (long long)b * S;
+  const float c = p.scale * 1.4426950408889634f;
+
+  // Q fragments stay resident; dO fragments are re-read per K/V tile (L1/L2 hits) to stay
+  // under 256 VGPRs without spilling.
+  bf16x8 qf[2][KS];
+  float lse2[2], dl[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qw0 + qt * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (q < S) qf[qt][ks] = *(const bf16x8*)(p.Q + (tok0 + q) * p.ldq + h * HD + ks * 32 + g * 8);
+      else qf[qt][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const long long si = ((long long)b * p.nh + h) * S + min(q, S - 1);
+    lse2[qt] = p.LSE[si] * 1.4426950408889634f;
+    dl[qt] = p.Delta[si];
+  }
+  f32x4 dq[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[qt][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
+  const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + HD) * 2), 0x00020000);
+  const int kv_end = CAUSAL ? min(q0 + 128, len) : len;
+  const int ntiles = (kv_end + 63) >> 6;
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int kv0 = j * 64;
+    __syncthreads();
+    stage_rows<HD>(rsK, sK, wave, lane, kv0, S, p.ldk);
+    stage_rows<HD>(rsV, sV, wave, lane, kv0, S, p.ldv);
+    stage_transposed<HD>(Kb + (long long)kv0 * p.ldk, p.ldk, S - kv0, sKt, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (CAUSAL && kv0 > qw0 + 31) continue;
+
+    // q-tiles are processed one after the other to keep S / dP live ranges at 32 registers
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x4 s[4], dp[4];
+      const int q = qw0 + qt * 16 + li;
+      const bf16_t* dop = p.dO + (tok0 + min(q, S - 1)) * p.lddo + h * HD + g * 8;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 dofr = *(const bf16x8*)(dop + ks * 32);   // rows q >= S are masked below
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const bf16x8 kf = read_rows<HD>(sK, nt * 16 + li, ks * 4 + g);
+          const bf16x8 vf = read_rows<HD>(sV, nt * 16 + li, ks * 4 + g);
+          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[nt], 0, 0, 0);
+          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dofr, dp[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + nt * 16 + g * 4 + r;
+          float pv = __builtin_amdgcn_exp2f(s[nt][r] * c - lse2[qt]);
+          if (key >= len || (CAUSAL && key > q) || q >= S) pv = 0.f;
+          s[nt][r] = pv * (dp[nt][r] - dl[qt]);
+        }
+      dsf[qt][0] = pack_frag(s[0], s[1]);
+      dsf[qt][1] = pack_frag(s[2], s[3]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16x8 ktf = read_transposed(sKt, d, st, li, g);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][st], dq[qt][d], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qw0 + qt * 16 + li;
+    if (q >= S) continue;
+    bf16_t* op = p.dQ + (tok0 + q) * p.lddq + h * HD + g * 16;
+#pragma unroll
+    for (int sp = 0; sp < HD / 64; ++sp) {
+      u32x4 w0, w1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        w0[k * 2] = pack2bf(dq[qt][sp * 4 + k][0] * p.scale, dq[qt][sp * 4 + k][1] * p.scale);
+        w0[k * 2 + 1] = pack2bf(dq[qt][sp * 4 + k][2] * p.scale, dq[qt][sp * 4 + k][3] * p.scale);
+        w1[k * 2] = pack2bf(dq[qt][sp * 4 + 2 + k][0] * p.scale, dq[qt][sp * 4 + 2 + k][1] * p.scale);
+        w1[k * 2 + 1] = pack2bf(dq[qt][sp * 4 + 2 + k][2] * p.scale, dq[qt][sp * 4 + 2 + k][3] * p.scale);
+      }
+      *(u32x4*)(op + sp * 64) = w0;
+      *(u32x4*)(op + sp * 64 + 8) = w1;
+    }
+  }
+}
+
+// ============================================================================ backward: dK, dV
+// One block = 64 keys of one (b, kv head): 4 waves x 16 keys; loops over the q heads of the GQA
+// group and over Q / dO tiles of 64 queries.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
+  constexpr int KS = HD / 32, DT = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sdO = smem + 64 * HD * 2;
+  char* sQt = smem + 2 * 64 * HD * 2;
+  char* sdOt = sQt + HD * TP;
+  float* sLse = (float*)(sdOt + HD * TP);
+  float* sDl = sLse + 64;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int S = p.S;
+  const int len = p.seqlens ? min(p.seqlens[b], S) : S;
+  const int k0 = kb * 64, kw0 = k0 + wave * 16;
+  const int key = kw0 + li;
+  const long long tok0 = (long long)b * S;
+  const float c = p.scale * 1.4426950408889634f;
+
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (key < S) {
+      kf[ks] = *(const bf16x8*)(p.K + (tok0 + key) * p.ldk + hk * HD + ks * 32 + g * 8);
+      vf[ks] = *(const bf16x8*)(p.V + (tok0 + key) * p.ldv + hk * HD + ks * 32 + g * 8);
+    } else {
+      kf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      vf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  const int nq = (S + 63) >> 6;
+  const int qt_first = CAUSAL ? (k0 >> 6) : 0;
+  const bool live_block = k0 < len;
+
+  for (int hh = 0; hh < p.group && live_block; ++hh) {
+    const int h = hk * p.group + hh;
+    const bf16_t* Qb = p.Q + tok0 * p.ldq + h * HD;
+    const bf16_t* dOb = p.dO + tok0 * p.lddo + h * HD;
+    __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)(((long long)(S - 1) * p.ldq + HD) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)dOb, 0, (int)(((long long)(S - 1) * p.lddo + HD) * 2), 0x00020000);
+    const float* lseb = p.LSE + ((long long)b * p.nh + h) * S;
+    const float* dlb = p.Delta + ((long long)b * p.nh + h) * S;
+    for (int j = qt_first; j < nq; ++j) {
+      const int q0 = j * 64;
+      __syncthreads();
+      stage_rows<HD>(rsQ, sQ, wave, lane, q0, S, p.ldq);
+      stage_rows<HD>(rsO, sdO, wave, lane, q0, S, p.lddo);
+      stage_transposed<HD>(Qb + (long long)q0 * p.ldq, p.ldq, S - q0, sQt, tid);
+      stage_transposed<HD>(dOb + (long long)q0 * p.lddo, p.lddo, S - q0, sdOt, tid);
+      if (tid < 64) sLse[tid] = (q0 + tid < S) ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
+      else if (tid < 128) sDl[tid - 64] = (q0 + tid - 64 < S) ? dlb[q0 + tid - 64] : 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (CAUSAL && q0 + 63 < kw0) continue;     // every query of the tile precedes this wave's keys
+
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { s[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 qfr = read_rows<HD>(sQ, t * 16 + li, ks * 4 + g);
+          const bf16x8 dofr = read_rows<HD>(sdO, t * 16 + li, ks * 4 + g);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[ks], s[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[ks], dp[t], 0, 0, 0);
+        }
+      // lane holds queries q0 + t*16 + g*4 + r (r=0..3) for ONE key (li)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 l4 = *(const f32x4*)(sLse + t * 16 + g * 4);
+        const f32x4 d4 = *(const f32x4*)(sDl + t * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = q0 + t * 16 + g * 4 + r;
+          float pv = __builtin_amdgcn_exp2f(s[t][r] * c - l4[r]);
+          if (q >= S || key >= len || (CAUSAL && key > q)) pv = 0.f;
+          s[t][r] = pv;
+          dp[t][r] = pv * (dp[t][r] - d4[r]);
+        }
+      }
+      const bf16x8 pf0 = pack_frag(s[0], s[1]), pf1 = pack_frag(s[2], s[3]);
+      const bf16x8 ds0 = pack_frag(dp[0], dp[1]), ds1 = pack_frag(dp[2], dp[3]);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16x8 o0 = read_transposed(sdOt, d, 0, li, g), o1 = read_transposed(sdOt, d, 1, li, g);
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[d], 0, 0, 0);
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[d], 0, 0, 0);
+        const bf16x8 t0 = read_transposed(sQt, d, 0, li, g), t1 = read_transposed(sQt, d, 1, li, g);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, ds0, dk[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, ds1, dk[d], 0, 0, 0);
+      }
+    }
+  }
+  if (key < S) {
+    bf16_t* kp = p.dK + (tok0 + key) * p.lddk + hk * HD + g * 16;
+    bf16_t* vp = p.dV + (tok0 + key) * p.lddv + hk * HD + g * 16;
+#pragma unroll
+    for (int sp = 0; sp < HD / 64; ++sp) {
+      u32x4 a0, a1, b0, b1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        a0[k * 2] = pack2bf(dk[sp * 4 + k][0] * p.scale, dk[sp * 4 + k][1] * p.scale);
+        a0[k * 2 + 1] = pack2bf(dk[sp * 4 + k][2] * p.scale, dk[sp * 4 + k][3] * p.scale);
+        a1[k * 2] = pack2bf(dk[sp * 4 + 2 + k][0] * p.scale, dk[sp * 4 + 2 + k][1] * p.scale);
+        a1[k * 2 + 1] = pack2bf(dk[sp * 4 + 2 + k][2] * p.scale, dk[sp * 4 + 2 + k][3] * p.scale);
+        b0[k * 2] = pack2bf(dv[sp * 4 + k][0], dv[sp * 4 + k][1]);
+        b0[k * 2 + 1] = pack2bf(dv[sp * 4 + k][2], dv[sp * 4 + k][3]);
+        b1[k * 2] = pack2bf(dv[sp * 4 + 2 + k][0], dv[sp * 4 + 2 + k][1]);
+        b1[k * 2 + 1] = pack2bf(dv[sp * 4 + 2 + k][2], dv[sp * 4 + 2 + k][3]);
+      }
+      *(u32x4*)(kp + sp * 64) = a0; *(u32x4*)(kp + sp * 64 + 8) = a1;
+      *(u32x4*)(vp + sp * 64) = b0; *(u32x4*)(vp + sp * 64 + 8) = b1;
+    }
+  }
+}
+
+template <typename KT>
+static int set_lds(KT kern, int bytes) {
+  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+static int check_common(int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv) {
+  if (B <= 0 || S <= 0 || nh <= 0 || nkv <= 0 || nh % nkv) return LMOD_EINVAL;
+  if (hd != 64 && hd != 128) return LMOD_EUNSUPPORTED;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || ldq < nh * hd || ldk < nkv * hd || ldv < nkv * hd) return LMOD_EINVAL;
+  if ((long long)S * ldk * 2 >= 0x7fffffffLL || (long long)S * ldq * 2 >= 0x7fffffffLL || (long long)S * ldv * 2 >= 0x7fffffffLL)
+    return LMOD_EUNSUPPORTED;
+  return LMOD_OK;
+}
+
+extern "C" {
+
+// Q [B*S, ldq] (head h at column h*hd), K/V [B*S, ldk/ldv] (kv head at column hk*hd); O [B*S, ldo];
+// lse [B, nh, S] fp32 (natural log of the scaled-score partition function; may be NULL).
+// seqlens [B] i32 or NULL: keys >= seqlens[b] are masked.
+int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens, int B, int S,
+                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
+                  hipStream_t stream) {
+  if (!Q || !K || !V || !O) return LMOD_EINVAL;
+  int rc = check_common(B, S, nh, nkv, hd, ldq, ldk, ldv);
+  if (rc) return rc;
+  if ((ldo & 7) || ldo < nh * hd) return LMOD_EINVAL;
+  AttnP p = {};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = lse;
+  p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
+  const dim3 grid((S + 127) / 128, nh, B);
+  const int lds = 64 * hd * 2 + hd * TP;
+  if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), lds, stream, p); }
+  else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), lds, stream, p); }
+  else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, stream, p); }
+  else { set_lds(attn_fwd_kernel<64, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), lds, stream, p); }
+  return lmod_launch_status();
+}
+
+// delta_ws: [B, nh, S] fp32 workspace.  dQ/dK/dV use the same layouts as Q/K/V (own leading dims).
+int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, int B, int S, int nh, int nkv,
+                  int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
+                  int causal, hipStream_t stream) {
+  if (!Q || !K || !V || !O || !dO || !lse || !delta_ws || !dQ || !dK || !dV) return LMOD_EINVAL;
+  int rc = check_common(B, S, nh, nkv, hd, ldq, ldk, ldv);
+  if (rc) return rc;
+  if ((ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7) || ldo < nh * hd || lddo < nh * hd ||
+      lddq < nh * hd || lddk < nkv * hd || lddv < nkv * hd) return LMOD_EINVAL;
+  if ((long long)S * lddo * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  AttnP p = {};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = (float*)lse;
+  p.dO = (const bf16_t*)dO; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
+  p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+  p.scale = scale;
+  const long long rows = (long long)B * S * nh;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dO,
+                     (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo);
+  const dim3 gq((S + 127) / 128, nh, B), gk((S + 63) / 64, nkv, B);
+  const int lds_q = 2 * 64 * hd * 2 + hd * TP;
+  const int lds_k = 2 * 64 * hd * 2 + 2 * hd * TP + 512;
+#define LAUNCH_BWD(HDV, CZ)                                                                                        \
+  do {                                                                                                             \
+    set_lds(attn_bwd_dq_kernel<HDV, CZ>, lds_q);                                                                   \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, CZ>), gq, dim3(256), lds_q, stream, p);                            \
+    set_lds(attn_bwd_dkv_kernel<HDV, CZ>, lds_k);                                                                  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, CZ>), gk, dim3(256), lds_k, stream, p);                           \
+  } while (0)
+  if (hd == 128 && causal) LAUNCH_BWD(128, true);
+  else if (hd == 128) LAUNCH_BWD(128, false);
+  else if (causal) LAUNCH_BWD(64, true);
+  else LAUNCH_BWD(64, false);
+#undef LAUNCH_BWD
+  return lmod_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] (+)= act(A[M,K] · B[N,K]^T + bias)
+//
+// "NT" form only: both operands are K-contiguous.  That is nn.Linear's forward as stored
+// (reference: qwen2/modeling_qwen2.py:262-264,320 QKV/O; :186-187 SwiGLU; :1163 lm_head;
+// multimodal_projector/builder.py:57-61; HF CLIP linears).  dgrad (dX = dY·W) and wgrad
+// (dW = dY^T·X) reach this kernel through lmod_transpose_bf16 (weights are transposed once per
+// optimizer step, activations per use) — see DESIGN.md "GEMM forms".
+//
+// Batched / grouped: `batch` problems with element strides; optional per-batch m_valid[] /
+// k_valid[] row / reduction extents make it the MoE expert grouped GEMM over [E, C, H] capacity
+// slabs (tiles past an expert's live rows exit immediately) — replaces DeepSpeed's per-expert
+// python loop (deepspeed.moe.experts, call site llava_qwen2_moe.py:536-546).
+//
+// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
+// Staging: buffer_load_dwordx4 ... lds (LDS-DMA), 2 LDS buffers, one barrier per K tile.
+// LDS image: [128 rows][8 chunks of 16 B], chunk XOR-swizzled by (row & 7); because LDS-DMA
+// writes lane-linear, the swizzle is applied to the per-lane SOURCE address and again on the
+// ds_read side (same involution).  B rows are additionally permuted at staging so that, with
+// the MFMA operands swapped (D = B_frag x A_frag = C^T tile), every lane ends up holding 16
+// CONTIGUOUS output columns of one output row -> 16-byte coalesced epilogue stores.
+#include "common.h"
+
+struct GemmP {
+  const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias;
+  int M, N, K, lda, ldb, ldc;
+  int batch; long long sA, sB, sC;
+  const int* m_valid; const int* k_valid;
+  int act;         // 0 none, 1 exact GELU, 2 quick_gelu
+  int out_f32;     // 0: bf16 C, 1: f32 C
+  int accumulate;  // C += result (read-modify-write)
+  int vec_ok;      // C pointer / ldc allow 16-byte vector stores
+  int tiles_m, tiles_n;
+};
+
+#define GEMM_OOB 0x80000000u
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  if (act == 2) return v / (1.f + __expf(-1.702f * v));
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB + B 16 KiB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile coordinates (XCD-contiguous, grouped along M for L2 panel reuse) ----
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpb = p.tiles_m * p.tiles_n;
+  const int bz = id / tpb;
+  const int r = id - bz * tpb;
+  const int GROUP_M = 8;
+  const int grp = r / (GROUP_M * p.tiles_n);
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int rr = r - grp * GROUP_M * p.tiles_n;
+  const int tm = first_m + rr % gsz, tn = rr / gsz;
+  int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
+  int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
+  const int row0 = tm * 128, col0 = tn * 128;
+  if (row0 >= Mv) return;
+
+  const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda;
+  const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb;
+  const int rowsA = min(128, Mv - row0), rowsB = min(128, p.N - col0);
+  const int Kv8 = (Kv + 7) & ~7;   // chunks are 8 elements; K % 8 == 0 so Kv8 <= K <= ld
+  const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
+  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)(rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
+
+  // ---- per-lane staging offsets (constant over the K loop; K advances through soffset) ----
+  // wave-load j of this wave fills LDS rows wave*32 + j*8 + (lane>>3), physical chunk lane&7.
+  const int cchunk = (lane & 7) ^ (lane >> 3);          // logical K chunk this lane fetches
+  uint32_t voA[4], voB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ra = wave * 32 + j * 8 + (lane >> 3);      // LDS row == tile row for A
+    voA[j] = (ra < rowsA) ? (uint32_t)((ra * p.lda + cchunk * 8) * 2) : GEMM_OOB;
+    const int rl = ra & 63, strip = ra >> 6;             // LDS row -> global column (permuted)
+    const int ii = rl & 15, ntl = rl >> 4;
+    const int nloc = strip * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);
+    voB[j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (Kv + 63) >> 6;
+
+  auto stage = [&](int t, int buf) {
+    const int k0 = t * 64;
+    char* sa = smem + buf * 32768 + wave * 4096;        // 32 rows x 128 B per wave
+    char* sb = sa + 16384;
+    const bool tail = (k0 + 64 > Kv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t va = voA[j], vb = voB[j];
+      if (tail && (k0 + cchunk * 8 >= Kv)) { va = GEMM_OOB; vb = GEMM_OOB; }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sa + j * 1024), 16, va, k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sb + j * 1024), 16, vb, k0 * 2, 0, 0);
+    }
+  };
+
+  // per-lane ds_read offsets: row (lane&15), logical chunk kk*4 + (lane>>4), swizzled by row&7.
+  const int rdrow = (lane & 15) * 128;
+  const int ph0 = (((lane >> 4)) ^ (lane & 7)) * 16;
+  const int ph1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
+
+  if (nkt > 0) stage(0, 0);
+  for (int t = 0; t < nkt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nkt) stage(t + 1, (t + 1) & 1);
+    const char* sa = smem + (t & 1) * 32768 + wm * 8192 + rdrow;
+    const char* sb = smem + (t & 1) * 32768 + 16384 + wn * 8192 + rdrow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ph = kk ? ph1 : ph0;
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(sa + i * 2048 + ph);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = *(const bf16x8*)(sb + i * 2048 + ph);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds, for each mt, row (lane&15) and 16 contiguous columns ----
+  const int g = lane >> 4;
+  const int cb = col0 + wn * 64 + g * 16;
+  float bia[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x) bia[x] = 0.f;
+  if (p.bias) {   // clamped index + select: no per-element branches
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float bv = bf2f(p.bias[min(cb + x, p.N - 1)]);
+      bia[x] = (cb + x < p.N) ? bv : 0.f;
+    }
+  }
+  char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : 2);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = row0 + wm * 64 + mt * 16 + (lane & 15);
+    if (row >= Mv) continue;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
+    if (p.act) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
+    }
+    const bool full = (cb + 16 <= p.N) && p.vec_ok;
+    if (p.out_f32) {
+      float* cp = (float*)Cb + (long long)row * p.ldc + cb;
+      if (full) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          f32x4 o = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+          if (p.accumulate) { f32x4 old = *(f32x4*)(cp + 4 * x); o += old; }
+          *(f32x4*)(cp + 4 * x) = o;
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) if (cb + x < p.N) cp[x] = p.accumulate ? cp[x] + v[x] : v[x];
+      }
+    } else {
+      bf16_t* cp = (bf16_t*)Cb + (long long)row * p.ldc + cb;
+      if (full && !p.accumulate) {
+        u32x4 o0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        u32x4 o1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+        *(u32x4*)(cp) = o0;
+        *(u32x4*)(cp + 8) = o1;
+      } else {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+          if (cb + x < p.N) cp[x] = f2bf(p.accumulate ? bf2f(cp[x]) + v[x] : v[x]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 transpose  out[C, ld_out] = in[R, C]^T  (batched).  Each thread transposes an 8x8 block in
+// registers: 8 x 16-byte loads (row-contiguous), 8 x 16-byte stores; lanes are laid out 8 x 8 so
+// both sides move whole 128-byte lines.  Columns R..ld_out-1 of `out` are written as zeros so the
+// result can be used directly as a K-contiguous GEMM operand with K = roundup(R, 8).
+// Requires C % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0, ld_out >= roundup(R, 8).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t a = in[2 * w][j >> 1], b = in[2 * w + 1][j >> 1];
+      o[w] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[j] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                            int R, int C, int ld_in, int ld_out,
+                                                            long long s_in, long long s_out, int tiles_c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bz = blockIdx.y;
+  const int tile = blockIdx.x * 4 + wave;               // one 64x64 tile per wave
+  const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+  const int r0 = tr * 64 + (lane >> 3) * 8, c0 = tc * 64 + (lane & 7) * 8;
+  if (c0 >= C || r0 >= ld_out) return;
+  const bf16_t* ip = in + (long long)bz * s_in;
+  bf16_t* op = out + (long long)bz * s_out;
+  u32x4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (r0 + i < R) a[i] = *(const u32x4*)(ip + (long long)(r0 + i) * ld_in + c0);
+    else a[i] = (u32x4){0u, 0u, 0u, 0u};
+  }
+  transpose8x8(a, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *(u32x4*)(op + (long long)(c0 + j) * ld_out + r0) = b[j];
+}
+
+extern "C" {
+
+int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
+                      int M, int N, int K, int lda, int ldb, int ldc,
+                      int batch, long long strideA, long long strideB, long long strideC,
+                      const int* m_valid, const int* k_valid,
+                      int act, int out_f32, int accumulate, hipStream_t stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return LMOD_EINVAL;
+  if (act < 0 || act > 2) return LMOD_EINVAL;
+  if ((long long)127 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  if ((long long)127 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = (const bf16_t*)bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
+  p.m_valid = m_valid; p.k_valid = k_valid;
+  p.act = act; p.out_f32 = out_f32; p.accumulate = accumulate;
+  const int esz = out_f32 ? 4 : 2;
+  p.vec_ok = (((uintptr_t)C & 15) == 0) && ((((long long)ldc * esz) & 15) == 0) &&
+             (((strideC * esz) & 15) == 0);
+  p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_128, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  return lmod_launch_status();
+}
+
+int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int ld_out,
+                        int batch, long long stride_in, long long stride_out, hipStream_t stream) {
+  if (!in || !out || R < 0 || C < 0) return LMOD_EINVAL;
+  if (R == 0 || C == 0 || batch == 0) return LMOD_OK;
+  if ((C & 7) || (ld_in & 7) || (ld_out & 7) || ld_in < C || ld_out < ((R + 7) & ~7)) return LMOD_EINVAL;
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15) || (stride_in & 7) || (stride_out & 7)) return LMOD_EINVAL;
+  const int tiles_r = (ld_out + 63) / 64, tiles_c = (C + 63) / 64;
+  const int tiles = tiles_r * tiles_c;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, stream,
+                     (const bf16_t*)in, (bf16_t*)out, R, C, ld_in, ld_out, stride_in, stride_out, tiles_c);
+  return lmod_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// Sparse-MoE routing kernels (gfx950): a sparse restatement of DeepSpeed-0.9.5's dense one-hot
+// MoE (deepspeed.moe.sharded_moe.{TopKGate, top2gating, MOELayer} — third-party, pinned by
+// reference requirements.txt:9; constructed at llava_qwen2_moe.py:536-546, result consumed at
+// :161-167).  DeepSpeed builds [S,E,C] one-hot dispatch/combine tensors and two einsums; here the
+// same decisions (which tokens keep a capacity slot, in token order) are produced as index maps:
+//   router_fwd   logits[T,E] = x.float() @ wg^T                (fp32, wave per 4 tokens)
+//   gate_top2    softmax, 1st/2nd expert (2nd over logits + noise with the 1st masked)
+//   scan         token-order exclusive prefix per expert (cumsum semantics), me/ce sums, l_aux
+//   finalize     capacity drop, renormalised combine weights, slot maps
+//   combine_fwd/bwd, dispatch_bwd(+router dx), router_wgrad
+// Dispatch itself is lmod_gather_rows with slot_token as the index (empty slots -> zero rows).
+#include "common.h"
+
+#define MAXE 8
+
+// ---------------------------------------------------------------- router logits (fp32)
+__global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wg,
+                                                        float* __restrict__ logits, int T, int H, int E) {
+  const int lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;     // 4 tokens per wave
+  if (t0 >= T) return;
+  float acc[4][MAXE];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) acc[a][e] = 0.f;
+  const int nch = H >> 3;
+  for (int c = lane; c < nch; c += 64) {
+    float xv[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (t0 + a < T) {
+        const u32x4 v = *(const u32x4*)(x + (long long)(t0 + a) * H + c * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xv[a][2 * k] = bflo(v[k]); xv[a][2 * k + 1] = bfhi(v[k]); }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[a][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E) {
+        const f32x4 w0 = *(const f32x4*)(wg + (long long)e * H + c * 8);
+        const f32x4 w1 = *(const f32x4*)(wg + (long long)e * H + c * 8 + 4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          acc[a][e] += xv[a][0] * w0[0] + xv[a][1] * w0[1] + xv[a][2] * w0[2] + xv[a][3] * w0[3] +
+                       xv[a][4] * w1[0] + xv[a][5] * w1[1] + xv[a][6] * w1[2] + xv[a][7] * w1[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E) {
+        const float s = wave_sum(acc[a][e]);
+        if (lane == 0 && t0 + a < T) logits[(long long)(t0 + a) * E + e] = s;
+      }
+    }
+}
+
+// ---------------------------------------------------------------- per-token softmax + top-2 picks
+__global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
+                                                       float* __restrict__ gates, int* __restrict__ idx1,
+                                                       int* __restrict__ idx2, int T, int E, int k) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float l[MAXE], g[MAXE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { l[e] = (e < E) ? logits[(long long)t * E + e] : -INFINITY; mx = fmaxf(mx, l[e]); }
+  float z = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { g[e] = (e < E) ? expf(l[e] - mx) : 0.f; z += g[e]; }
+  int i1 = 0; float b1 = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    g[e] /= z;
+    if (e < E) { gates[(long long)t * E + e] = g[e]; if (g[e] > b1) { b1 = g[e]; i1 = e; } }  // first max wins
+  }
+  idx1[t] = i1;
+  if (k >= 2) {
+    int i2 = 0; float b2 = -INFINITY; bool any = false;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E && e != i1) {
+        const float v = l[e] + (noise ? noise[(long long)t * E + e] : 0.f);
+        if (!any || v > b2) { b2 = v; i2 = e; any = true; }
+      }
+    }
+    idx2[t] = i2;
+  }
+}
+
+// ---------------------------------------------------------------- token-order prefix (single block)
+// loc1[t] = #{t' < t : idx1[t'] == idx1[t]} ; loc2[t] = #{t' < t : idx2[t'] == idx2[t]} + count1[idx2[t]]
+// (cumsum(mask,0)-1 and the "+ sum(mask1)" offset of top2gating).  Also exp_counts, sum of gates per
+// expert (me*T) and l_aux = mean(me*ce)*E*E.
+__global__ __launch_bounds__(1024) void moe_scan_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
+                                                       const float* __restrict__ gates, int* __restrict__ loc1,
+                                                       int* __restrict__ loc2, int* __restrict__ exp_counts,
+                                                       float* __restrict__ gate_sum, float* __restrict__ l_aux,
+                                                       int T, int E, int k) {
+  extern __shared__ int sh[];                // [2*MAXE][1024] counts, then scratch
+  int* cnt = sh;                             // cnt[(j*MAXE+e)*1024 + tid]
+  float* gsum = (float*)(sh + 2 * MAXE * 1024);   // [MAXE][16] per-wave partials
+  const int tid = threadIdx.x;
+  const int chunk = (T + 1023) / 1024;
+  const int lo = min(tid * chunk, T), hi = min(lo + chunk, T);
+  int c1[MAXE], c2[MAXE]; float gs[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { c1[e] = 0; c2[e] = 0; gs[e] = 0.f; }
+  for (int t = lo; t < hi; ++t) {
+    const int a = idx1[t];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      c1[e] += (a == e);
+      if (e < E) gs[e] += gates[(long long)t * E + e];
+    }
+    if (k >= 2) { const int b = idx2[t];
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) c2[e] += (b == e); }
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { cnt[e * 1024 + tid] = c1[e]; cnt[(MAXE + e) * 1024 + tid] = c2[e]; }
+  // gate sums: wave reduce then 16 partials
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const float s = wave_sum(gs[e]);
+    if ((tid & 63) == 0) gsum[e * 16 + (tid >> 6)] = s;
+  }
+  __syncthreads();
+  // exclusive scan of each of the 2*MAXE rows over 1024 entries: wave w scans row w (16 rows, 16 waves)
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    int* row = cnt + w * 1024;
+    int carry = 0;
+    for (int base = 0; base < 1024; base += 64) {
+      const int v = row[base + lane];
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+      row[base + lane] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+    // row total == carry (held by every lane of wave w)
+    if (lane == 0) gsum[MAXE * 16 + w] = __int_as_float(carry);
+  }
+  __syncthreads();
+  int tot1[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) tot1[e] = __float_as_int(gsum[MAXE * 16 + e]);
+  // second pass: assign locations
+  int r1[MAXE], r2[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { r1[e] = cnt[e * 1024 + tid]; r2[e] = cnt[(MAXE + e) * 1024 + tid] + tot1[e]; }
+  for (int t = lo; t < hi; ++t) {
+    const int a = idx1[t];
+    int v = 0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) if (a == e) { v = r1[e]; r1[e]++; }
+    loc1[t] = v;
+    if (k >= 2) {
+      const int b = idx2[t];
+      int u = 0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) if (b == e) { u = r2[e]; r2[e]++; }
+      loc2[t] = u;
+    }
+  }
+  if (tid == 0) {
+    float la = 0.f;
+    for (int e = 0; e < E; ++e) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += gsum[e * 16 + w];
+      gate_sum[e] = s;
+      exp_counts[e] = tot1[e];
+      la += (s / (float)T) * ((float)tot1[e] / (float)T);
+    }
+    // top2gating: mean(me*ce)*E*E ; top1gating: sum(me*ce)*E — both equal E * sum_e(me*ce)
+    l_aux[0] = la * (float)E;
+  }
+}
+
+// ---------------------------------------------------------------- capacity drop + combine weights + slot maps
+__global__ __launch_bounds__(256) void moe_finalize_kernel(const float* __restrict__ gates, const int* __restrict__ idx1,
+                                                          const int* __restrict__ idx2, const int* __restrict__ loc1,
+                                                          const int* __restrict__ loc2, int* __restrict__ slot1,
+                                                          int* __restrict__ slot2, float* __restrict__ w1,
+                                                          float* __restrict__ w2, int* __restrict__ slot_token,
+                                                          float* __restrict__ slot_w, int T, int E, int C, int k) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int e1 = idx1[t], l1 = loc1[t];
+  const bool k1 = l1 < C;
+  float g1 = k1 ? gates[(long long)t * E + e1] : 0.f;
+  float g2 = 0.f; int e2 = 0, l2 = 0; bool k2 = false;
+  if (k >= 2) { e2 = idx2[t]; l2 = loc2[t]; k2 = l2 < C; g2 = k2 ? gates[(long long)t * E + e2] : 0.f; }
+  float a1 = g1, a2 = g2;
+  if (k >= 2) {                                   // top-2 renormalises over the surviving picks
+    const float den = fmaxf(g1 + g2, 1.1920929e-07f);
+    a1 = g1 / den; a2 = g2 / den;
+  }
+  const int s1 = k1 ? e1 * C + l1 : -1;
+  const int s2 = k2 ? e2 * C + l2 : -1;
+  slot1[t] = s1; w1[t] = a1;
+  if (k >= 2) { slot2[t] = s2; w2[t] = a2; }
+  if (k1) { slot_token[s1] = t; slot_w[s1] = a1; }
+  if (k2) { slot_token[s2] = t; slot_w[s2] = a2; }
+}
+
+// ---------------------------------------------------------------- combine: out[t] = bf(w1)*y[s1] + bf(w2)*y[s2]
+// (combine_weights.type_as(x) in MOELayer.forward -> the weights are rounded to bf16 first)
+__global__ __launch_bounds__(256) void moe_combine_fwd_kernel(const bf16_t* __restrict__ y, const int* __restrict__ slot1,
+                                                             const int* __restrict__ slot2, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, bf16_t* __restrict__ out,
+                                                             long long T, int H) {
+  const int nch = H >> 3;
+  const long long total = T * nch;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const long long t = id / nch; const int c = (int)(id - t * nch) * 8;
+    const int s1 = slot1[t], s2 = slot2 ? slot2[t] : -1;
+    const float a1 = (s1 >= 0) ? bfround(w1[t]) : 0.f, a2 = (s2 >= 0) ? bfround(w2[t]) : 0.f;
+    u32x4 v1 = {0u, 0u, 0u, 0u}, v2 = {0u, 0u, 0u, 0u};
+    if (s1 >= 0) v1 = *(const u32x4*)(y + (long long)s1 * H + c);
+    if (s2 >= 0) v2 = *(const u32x4*)(y + (long long)s2 * H + c);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = pack2bf(a1 * bflo(v1[k]) + a2 * bflo(v2[k]), a1 * bfhi(v1[k]) + a2 * bfhi(v2[k]));
+    *(u32x4*)(out + t * H + c) = o;
+  }
+}
+
+// combine backward, slot side: dy[slot] = bf(slot_w) * dout[slot_token]  (zero rows for empty slots)
+__global__ __launch_bounds__(256) void moe_combine_bwd_slots_kernel(const bf16_t* __restrict__ dout,
+                                                                   const int* __restrict__ slot_token,
+                                                                   const float* __restrict__ slot_w,
+                                                                   bf16_t* __restrict__ dy, long long S, int H) {
+  const int nch = H >> 3;
+  const long long total = S * nch;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const long long s = id / nch; const int c = (int)(id - s * nch) * 8;
+    const int t = slot_token[s];
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (t >= 0) {
+      const float a = bfround(slot_w[s]);
+      const u32x4 v = *(const u32x4*)(dout + (long long)t * H + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack2bf(a * bflo(v[k]), a * bfhi(v[k]));
+    }
+    *(u32x4*)(dy + s * H + c) = o;
+  }
+}
+
+// combine backward, weight side: dw_j[t] = <dout[t], y[slot_j(t)]>   (wave per token)
+__global__ __launch_bounds__(256) void moe_combine_bwd_w_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                               const int* __restrict__ slot1, const int* __restrict__ slot2,
+                                                               float* __restrict__ dw1, float* __restrict__ dw2, int T, int H) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int s1 = slot1[t], s2 = slot2 ? slot2[t] : -1;
+  float a1 = 0.f, a2 = 0.f;
+  const int nch = H >> 3;
+  for (int c = lane; c < nch; c += 64) {
+    const u32x4 d = *(const u32x4*)(dout + (long long)t * H + c * 8);
+    if (s1 >= 0) {
+      const u32x4 v = *(const u32x4*)(y + (long long)s1 * H + c * 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a1 += bflo(d[k]) * bflo(v[k]) + bfhi(d[k]) * bfhi(v[k]);
+    }
+    if (s2 >= 0) {
+      const u32x4 v = *(const u32x4*)(y + (long long)s2 * H + c * 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a2 += bflo(d[k]) * bflo(v[k]) + bfhi(d[k]) * bfhi(v[k]);
+    }
+  }
+  a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) { dw1[t] = a1; if (dw2) dw2[t] = a2; }
+}
+
+// gate backward: (dw1, dw2, d l_aux) -> dlogits[T,E]
+__global__ __launch_bounds__(256) void moe_gate_bwd_kernel(const float* __restrict__ gates, const int* __restrict__ idx1,
+                                                          const int* __restrict__ idx2, const int* __restrict__ slot1,
+                                                          const int* __restrict__ slot2, const float* __restrict__ dw1,
+                                                          const float* __restrict__ dw2, const int* __restrict__ exp_counts,
+                                                          const float* __restrict__ d_laux, float* __restrict__ dlogits,
+                                                          int T, int E, int k) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float g[MAXE], dg[MAXE];
+  const float dla = d_laux ? d_laux[0] : 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    g[e] = (e < E) ? gates[(long long)t * E + e] : 0.f;
+    // l_aux = E * sum_e (sum_t gates[t,e]/T) * (count1[e]/T)
+    dg[e] = (e < E) ? dla * (float)E * ((float)exp_counts[e] / (float)T) / (float)T : 0.f;
+  }
+  const int e1 = idx1[t];
+  const bool k1 = slot1[t] >= 0;
+  if (k >= 2) {
+    const int e2 = idx2[t];
+    const bool k2 = slot2[t] >= 0;
+    const float g1 = k1 ? g[e1] : 0.f, g2 = k2 ? g[e2] : 0.f;
+    const float sum = g1 + g2;
+    if (sum > 1.1920929e-07f) {
+      const float u1 = dw1[t], u2 = dw2[t];
+      const float common = (u1 * g1 + u2 * g2) / (sum * sum);
+      const float d1 = u1 / sum - common, d2 = u2 / sum - common;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) { if (k1 && e == e1) dg[e] += d1; if (k2 && e == e2) dg[e] += d2; }
+    }
+  } else {
+    const float u1 = dw1[t];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) if (k1 && e == e1) dg[e] += u1;
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) dot += g[e] * dg[e];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) if (e < E) dlogits[(long long)t * E + e] = g[e] * (dg[e] - dot);
+}
+
+// dx[t] = d_in[slot1(t)] + d_in[slot2(t)] + bf16( sum_e dlogits[t,e] * wg[e] )   (dispatch is a copy)
+__global__ __launch_bounds__(256) void moe_dispatch_bwd_kernel(const bf16_t* __restrict__ d_in, const int* __restrict__ slot1,
+                                                              const int* __restrict__ slot2, const float* __restrict__ dlogits,
+                                                              const float* __restrict__ wg, bf16_t* __restrict__ dx,
+                                                              long long T, int H, int E) {
+  const int nch = H >> 3;
+  const long long total = T * nch;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const long long t = id / nch; const int c = (int)(id - t * nch) * 8;
+    const int s1 = slot1[t], s2 = slot2 ? slot2[t] : -1;
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = 0.f;
+    if (dlogits) {
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        if (e < E) {
+          const float dl = dlogits[t * E + e];
+          const f32x4 a = *(const f32x4*)(wg + (long long)e * H + c);
+          const f32x4 b = *(const f32x4*)(wg + (long long)e * H + c + 4);
+          r[0] += dl * a[0]; r[1] += dl * a[1]; r[2] += dl * a[2]; r[3] += dl * a[3];
+          r[4] += dl * b[0]; r[5] += dl * b[1]; r[6] += dl * b[2]; r[7] += dl * b[3];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = bfround(r[k]);
+    }
+    if (s1 >= 0) {
+      const u32x4 v = *(const u32x4*)(d_in + (long long)s1 * H + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r[2 * k] += bflo(v[k]); r[2 * k + 1] += bfhi(v[k]); }
+    }
+    if (s2 >= 0) {
+      const u32x4 v = *(const u32x4*)(d_in + (long long)s2 * H + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r[2 * k] += bflo(v[k]); r[2 * k + 1] += bfhi(v[k]); }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2bf(r[2 * k], r[2 * k + 1]);
+    *(u32x4*)(dx + t * H + c) = o;
+  }
+}
+
+// router wgrad: partial[slab][e][h] = sum_{t in slab} dlogits[t,e] * x[t,h] ; then reduced into dwg (+=)
+#define WG_SLAB 256
+__global__ __launch_bounds__(256) void router_wgrad_partial_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dlogits,
+                                                                  float* __restrict__ partial, int T, int H, int E) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  const int slab = blockIdx.y;
+  if (h >= H) return;
+  const int lo = slab * WG_SLAB, hi = min(lo + WG_SLAB, T);
+  float acc[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
+  for (int t = lo; t < hi; ++t) {
+    const float xv = bf2f(x[(long long)t * H + h]);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) if (e < E) acc[e] += dlogits[(long long)t * E + e] * xv;
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) if (e < E) partial[((long long)slab * E + e) * H + h] = acc[e];
+}
+__global__ __launch_bounds__(256) void router_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dwg,
+                                                                 int nslab, int EH, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= EH) return;
+  float s = 0.f;
+  for (int b = 0; b < nslab; ++b) s += partial[(long long)b * EH + i];
+  dwg[i] = accumulate ? dwg[i] + s : s;
+}
+
+static inline int grid_for(long long work, int cap = 256 * 16) {
+  long long b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+extern "C" {
+
+int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream) {
+  if (!x || !wg || !logits || T < 0 || H <= 0 || (H & 7) || E <= 0 || E > MAXE) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  hipLaunchKernelGGL(router_fwd_kernel, dim3((T + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, wg, logits, T, H, E);
+  return lmod_launch_status();
+}
+
+// Full gating decision from logits.  noise: [T,E] additive (Gumbel) noise for the 2nd pick, or NULL.
+// Outputs: gates[T,E] f32; idx1/idx2/slot1/slot2 [T] i32; w1/w2 [T] f32; slot_token [E*C] i32 (-1 empty);
+// slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.  scratch: 2*T i32 (loc1, loc2).
+int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
+                  int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
+                  int* exp_counts, float* gate_sum, float* l_aux, int* scratch, hipStream_t stream) {
+  if (!logits || !gates || !idx1 || !slot1 || !w1 || !slot_token || !slot_w || !exp_counts || !gate_sum || !l_aux ||
+      !scratch || T <= 0 || E <= 0 || E > MAXE || (k != 1 && k != 2) || C <= 0) return LMOD_EINVAL;
+  if (k == 2 && (!idx2 || !slot2 || !w2)) return LMOD_EINVAL;
+  int* loc1 = scratch; int* loc2 = scratch + T;
+  hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k);
+  const size_t sh = (size_t)2 * MAXE * 1024 * 4 + (MAXE * 16 + 16) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)moe_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), sh, stream, idx1, idx2, gates, loc1, loc2, exp_counts,
+                     gate_sum, l_aux, T, E, k);
+  if (hipMemsetAsync(slot_token, 0xFF, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
+  if (hipMemsetAsync(slot_w, 0, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
+  hipLaunchKernelGGL(moe_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, loc1, loc2,
+                     slot1, slot2, w1, w2, slot_token, slot_w, T, E, C, k);
+  return lmod_launch_status();
+}
+
+int lmod_moe_combine_fwd(const void* y, const int* slot1, const int* slot2, const float* w1, const float* w2,
+                         void* out, int T, int H, hipStream_t stream) {
+  if (!y || !slot1 || !w1 || !out || T < 0 || H <= 0 || (H & 7) || (slot2 && !w2)) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  hipLaunchKernelGGL(moe_combine_fwd_kernel, dim3(grid_for((long long)T * (H >> 3))), dim3(256), 0, stream,
+                     (const bf16_t*)y, slot1, slot2, w1, w2, (bf16_t*)out, (long long)T, H);
+  return lmod_launch_status();
+}
+
+int lmod_moe_combine_bwd(const void* dout, const void* y, const int* slot1, const int* slot2, const int* slot_token,
+                         const float* slot_w, void* dy, float* dw1, float* dw2, int T, int S, int H,
+                         hipStream_t stream) {
+  if (!dout || !y || !slot1 || !slot_token || !slot_w || !dy || !dw1 || T < 0 || S < 0 || H <= 0 || (H & 7))
+    return LMOD_EINVAL;
+  if (T == 0 || S == 0) return LMOD_OK;
+  hipLaunchKernelGGL(moe_combine_bwd_slots_kernel, dim3(grid_for((long long)S * (H >> 3))), dim3(256), 0, stream,
+                     (const bf16_t*)dout, slot_token, slot_w, (bf16_t*)dy, (long long)S, H);
+  hipLaunchKernelGGL(moe_combine_bwd_w_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, (const bf16_t*)dout,
+                     (const bf16_t*)y, slot1, slot2, dw1, dw2, T, H);
+  return lmod_launch_status();
+}
+
+int lmod_moe_gate_bwd(const float* gates, const int* idx1, const int* idx2, const int* slot1, const int* slot2,
+                      const float* dw1, const float* dw2, const int* exp_counts, const float* d_laux, float* dlogits,
+                      int T, int E, int k, hipStream_t stream) {
+  if (!gates || !idx1 || !slot1 || !dw1 || !exp_counts || !dlogits || T < 0 || E <= 0 || E > MAXE || (k != 1 && k != 2))
+    return LMOD_EINVAL;
+  if (k == 2 && (!idx2 || !slot2 || !dw2)) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  hipLaunchKernelGGL(moe_gate_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, slot1, slot2,
+                     dw1, dw2, exp_counts, d_laux, dlogits, T, E, k);
+  return lmod_launch_status();
+}
+
+int lmod_moe_dispatch_bwd(const void* d_in, const int* slot1, const int* slot2, const float* dlogits, const float* wg,
+                          void* dx, int T, int H, int E, hipStream_t stream) {
+  if (!d_in || !slot1 || !dx || T < 0 || H <= 0 || (H & 7) || (dlogits && (!wg || E <= 0 || E > MAXE))) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  hipLaunchKernelGGL(moe_dispatch_bwd_kernel, dim3(grid_for((long long)T * (H >> 3))), dim3(256), 0, stream,
+                     (const bf16_t*)d_in, slot1, slot2, dlogits, wg, (bf16_t*)dx, (long long)T, H, E);
+  return lmod_launch_status();
+}
+
+// workspace: ceil(T/256) * E * H floats
+int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float* workspace, int T, int H, int E,
+                          int accumulate, hipStream_t stream) {
+  if (!x || !dlogits || !dwg || !workspace || T < 0 || H <= 0 || E <= 0 || E > MAXE) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  const int nslab = (T + WG_SLAB - 1) / WG_SLAB;
+  hipLaunchKernelGGL(router_wgrad_partial_kernel, dim3((H + 255) / 256, nslab), dim3(256), 0, stream, (const bf16_t*)x,
+                     dlogits, workspace, T, H, E);
+  hipLaunchKernelGGL(router_wgrad_reduce_kernel, dim3((E * H + 255) / 256), dim3(256), 0, stream, workspace, dwg, nslab,
+                     E * H, accumulate);
+  return lmod_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI kernel library (include/lmod_hip.h).
+
+The product path has NO fallback: if ``liblmod_hip.so`` is missing or a symbol is absent, importing
+an op raises.  PyTorch is used here only to own device memory and the stream.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblmod_hip.so")
+
+_P, _I, _Q, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+# name -> argument type string (p pointer, i int, q long long, f float); every function returns int
+# and takes the hipStream_t last ('p').  Kept in the same order as include/lmod_hip.h.
+SIGNATURES = {
+    "lmod_gemm_bf16_nt": "pppp" + "iiiiii" + "iqqq" + "pp" + "iii" + "p",
+    "lmod_transpose_bf16": "pp" + "iiii" + "iqq" + "p",
+    "lmod_rmsnorm_fwd": "pppppp" + "iif" + "p",
+    "lmod_rmsnorm_bwd": "pppppp" + "ii" + "p",
+    "lmod_layernorm_fwd": "pppp" + "iif" + "p",
+    "lmod_rope": "pppp" + "iiiii" + "p",
+    "lmod_swiglu_fwd": "ppp" + "qiiii" + "p",
+    "lmod_swiglu_bwd": "ppppp" + "qiiiiii" + "p",
+    "lmod_gelu_fwd": "pp" + "q" + "p",
+    "lmod_gelu_bwd": "ppp" + "q" + "p",
+    "lmod_add_bf16": "ppp" + "q" + "p",
+    "lmod_gather_rows": "pppp" + "qi" + "p",
+    "lmod_im2col_patch": "pp" + "iiii" + "p",
+    "lmod_vit_embed": "pppp" + "iii" + "p",
+    "lmod_adamw_step": "ppppp" + "q" + "fffff" + "i" + "f" + "p",
+    "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
+    "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
+    "lmod_moe_router_fwd": "ppp" + "iii" + "p",
+    "lmod_moe_gate": "pp" + "iiii" + "ppppppppppppp" + "p",
+    "lmod_moe_combine_fwd": "pppppp" + "ii" + "p",
+    "lmod_moe_combine_bwd": "ppppppppp" + "iii" + "p",
+    "lmod_moe_gate_bwd": "pppppppppp" + "iii" + "p",
+    "lmod_moe_dispatch_bwd": "pppppp" + "iii" + "p",
+    "lmod_moe_router_wgrad": "pppp" + "iiii" + "p",
+    "lmod_rowloss_fwd": "pqi" + "pqi" + "pp" + "i" + "p",
+    "lmod_rowloss_bwd": "pqi" + "pqi" + "pp" + "ppppp" + "pq" + "i" + "p",
+    "lmod_segment_wsum": "pii" + "pp" + "i" + "pp" + "p",
+    "lmod_dpo_loss": "pppp" + "iffi" + "ppppp" + "p",
+}
+_CT = {"p": _P, "i": _I, "q": _Q, "f": _F}
+_ERR = {-1: "LMOD_EINVAL (bad pointer/shape/alignment)", -2: "LMOD_ELAUNCH (HIP launch error)",
+        -3: "LMOD_EUNSUPPORTED (outside compiled envelope)"}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP kernels first (python __graft_entry__.py build, or "
+            f"`make -C llava-mod_amd/csrc`).  There is no CPU/PyTorch fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud failure
+        fn.restype = _I
+        fn.argtypes = [_CT[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke `name` on the current torch stream; raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

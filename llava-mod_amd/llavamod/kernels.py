@@ -1,0 +1,293 @@
+"""Functional (non-autograd) wrappers over the C-ABI kernels: allocate outputs, pass raw pointers.
+
+Every function here launches hand-written HIP kernels through `_hip.call`; there is no torch
+compute in this file (torch only allocates device memory).  Tensors are bf16 unless noted.
+"""
+import torch
+
+from . import _hip
+from ._hip import call, ptr
+
+BF16 = torch.bfloat16
+
+
+def _chk(t, dtype=None):
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    if dtype is not None:
+        assert t.dtype == dtype, f"expected {dtype}, got {t.dtype}"
+    return t
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False, m_valid=None, k_valid=None,
+            M=None, N=None, K=None, lda=None, ldb=None, ldc=None, batch=1, strides=(0, 0, 0)):
+    """out[M,N] (+)= act(a[M,K] @ b[N,K]^T + bias).  2-D tensors by default; explicit dims/strides for
+    sub-matrix and batched (grouped) use."""
+    if M is None:
+        M, K = a.shape[-2], a.shape[-1]
+        N = b.shape[-2]
+        lda, ldb = a.stride(-2), b.stride(-2)
+        if a.dim() == 3:
+            batch = a.shape[0]
+            strides = (a.stride(0), b.stride(0) if b.dim() == 3 else 0, None)
+    if out is None:
+        shape = (batch, M, N) if (a.dim() == 3) else (M, N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    if ldc is None:
+        ldc = out.stride(-2)
+    sA, sB, sC = strides
+    if sC is None:
+        sC = out.stride(0) if out.dim() == 3 else 0
+    call("lmod_gemm_bf16_nt", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, lda, ldb, ldc, batch, sA, sB, sC,
+         ptr(m_valid), ptr(k_valid), act, int(out_f32), int(accumulate))
+    return out
+
+
+def transpose(x, ld_out=None, out=None):
+    """[.., R, C] -> [.., C, roundup(R,8)] (zero padded)."""
+    R, C = x.shape[-2], x.shape[-1]
+    batch = x.shape[0] if x.dim() == 3 else 1
+    if ld_out is None:
+        ld_out = (R + 7) // 8 * 8
+    if out is None:
+        shape = (batch, C, ld_out) if x.dim() == 3 else (C, ld_out)
+        out = torch.empty(shape, device=x.device, dtype=BF16)
+    call("lmod_transpose_bf16", ptr(x), ptr(out), R, C, x.stride(-2), ld_out, batch,
+         x.stride(0) if x.dim() == 3 else 0, out.stride(0) if out.dim() == 3 else 0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ rows
+def rmsnorm_fwd(x, w, eps, res=None, want_h=True):
+    T, H = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(T, device=x.device, dtype=torch.float32)
+    h = torch.empty_like(x) if (res is not None and want_h) else None
+    call("lmod_rmsnorm_fwd", ptr(x), ptr(res), ptr(w), ptr(h), ptr(y), ptr(rstd), T, H, float(eps))
+    return y, rstd, (h if res is not None else x)
+
+
+def rmsnorm_bwd(dy, h, w, rstd, dres=None):
+    T, H = h.shape
+    dh = torch.empty_like(h)
+    call("lmod_rmsnorm_bwd", ptr(dy), ptr(h), ptr(w), ptr(rstd), ptr(dres), ptr(dh), T, H)
+    return dh
+
+
+def layernorm_fwd(x, w, b, eps):
+    T, H = x.shape
+    y = torch.empty_like(x)
+    call("lmod_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), T, H, float(eps))
+    return y
+
+
+def rope_(buf, cos_t, sin_t, pos, nheads, hd, backward=False):
+    T, ld = buf.shape[0], buf.stride(0)
+    call("lmod_rope", ptr(buf), ptr(cos_t), ptr(sin_t), ptr(pos), T, nheads, hd, ld, int(backward))
+    return buf
+
+
+def swiglu_fwd(gate, up, out=None):
+    rows, I = gate.shape
+    if out is None:
+        out = torch.empty((rows, I), device=gate.device, dtype=BF16)
+    call("lmod_swiglu_fwd", ptr(gate), ptr(up), ptr(out), rows, I, gate.stride(0), up.stride(0), out.stride(0))
+    return out
+
+
+def swiglu_bwd(dact, gate, up, dgate=None, dup=None):
+    rows, I = gate.shape
+    if dgate is None:
+        dgate = torch.empty((rows, I), device=gate.device, dtype=BF16)
+    if dup is None:
+        dup = torch.empty((rows, I), device=gate.device, dtype=BF16)
+    call("lmod_swiglu_bwd", ptr(dact), ptr(gate), ptr(up), ptr(dgate), ptr(dup), rows, I, dact.stride(0),
+         gate.stride(0), up.stride(0), dgate.stride(0), dup.stride(0))
+    return dgate, dup
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    call("lmod_gelu_fwd", ptr(x), ptr(y), x.numel())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    call("lmod_gelu_bwd", ptr(dy), ptr(x), ptr(dx), x.numel())
+    return dx
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    call("lmod_add_bf16", ptr(a), ptr(b), ptr(out), a.numel())
+    return out
+
+
+def gather_rows(src_a, src_b, idx, H):
+    rows = idx.numel()
+    out = torch.empty((rows, H), device=idx.device, dtype=BF16)
+    call("lmod_gather_rows", ptr(src_a), ptr(src_b), ptr(idx), ptr(out), rows, H)
+    return out
+
+
+def im2col_patch(pixels, patch, kpad):
+    B, _, S, _ = pixels.shape
+    G = S // patch
+    out = torch.empty((B * G * G, kpad), device=pixels.device, dtype=BF16)
+    call("lmod_im2col_patch", ptr(pixels), ptr(out), B, S, patch, kpad)
+    return out
+
+
+def vit_embed(patch_emb, cls, pos, B, n_patches):
+    D = patch_emb.shape[-1]
+    out = torch.empty((B * (n_patches + 1), D), device=patch_emb.device, dtype=BF16)
+    call("lmod_vit_embed", ptr(patch_emb), ptr(cls), ptr(pos), ptr(out), B, n_patches, D)
+    return out
+
+
+def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("lmod_adamw_step", ptr(master), ptr(param), ptr(grad), ptr(m), ptr(v), master.numel(), float(lr),
+         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale))
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, B, S, nh, nkv, hd, scale, causal, seqlens=None, want_lse=True):
+    """q/k/v: 2-D views [B*S, ld] whose column 0 is head 0 (views into a fused QKV buffer are fine)."""
+    o = torch.empty((B * S, nh * hd), device=q.device, dtype=BF16)
+    lse = torch.empty((B, nh, S), device=q.device, dtype=torch.float32) if want_lse else None
+    call("lmod_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(seqlens), B, S, nh, nkv, hd, q.stride(0),
+         k.stride(0), v.stride(0), o.stride(0), float(scale), int(causal))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None):
+    delta = torch.empty((B, nh, S), device=q.device, dtype=torch.float32)
+    call("lmod_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+         ptr(seqlens), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+         dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------ MoE
+def moe_router_fwd(x, wg):
+    T, H = x.shape
+    E = wg.shape[0]
+    logits = torch.empty((T, E), device=x.device, dtype=torch.float32)
+    call("lmod_moe_router_fwd", ptr(x), ptr(wg), ptr(logits), T, H, E)
+    return logits
+
+
+class GateState:
+    """Index maps produced by lmod_moe_gate (all device tensors)."""
+    __slots__ = ("T", "E", "k", "C", "gates", "idx1", "idx2", "slot1", "slot2", "w1", "w2", "slot_token", "slot_w",
+                 "exp_counts", "gate_sum", "l_aux")
+
+
+def moe_gate(logits, k, C, noise=None):
+    T, E = logits.shape
+    dev = logits.device
+    st = GateState()
+    st.T, st.E, st.k, st.C = T, E, k, C
+    st.gates = torch.empty((T, E), device=dev, dtype=torch.float32)
+    i32 = dict(device=dev, dtype=torch.int32)
+    f32 = dict(device=dev, dtype=torch.float32)
+    st.idx1 = torch.empty(T, **i32); st.slot1 = torch.empty(T, **i32); st.w1 = torch.empty(T, **f32)
+    if k == 2:
+        st.idx2 = torch.empty(T, **i32); st.slot2 = torch.empty(T, **i32); st.w2 = torch.empty(T, **f32)
+    else:
+        st.idx2 = st.slot2 = st.w2 = None
+    st.slot_token = torch.empty(E * C, **i32); st.slot_w = torch.empty(E * C, **f32)
+    st.exp_counts = torch.empty(E, **i32); st.gate_sum = torch.empty(E, **f32); st.l_aux = torch.empty(1, **f32)
+    scratch = torch.empty(2 * T, **i32)
+    call("lmod_moe_gate", ptr(logits), ptr(noise), T, E, k, C, ptr(st.gates), ptr(st.idx1), ptr(st.idx2),
+         ptr(st.slot1), ptr(st.slot2), ptr(st.w1), ptr(st.w2), ptr(st.slot_token), ptr(st.slot_w),
+         ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(scratch))
+    return st
+
+
+def moe_combine_fwd(y, st, H):
+    out = torch.empty((st.T, H), device=y.device, dtype=BF16)
+    call("lmod_moe_combine_fwd", ptr(y), ptr(st.slot1), ptr(st.slot2), ptr(st.w1), ptr(st.w2), ptr(out), st.T, H)
+    return out
+
+
+def moe_combine_bwd(dout, y, st, H):
+    S = st.E * st.C
+    dy = torch.empty((S, H), device=y.device, dtype=BF16)
+    dw1 = torch.empty(st.T, device=y.device, dtype=torch.float32)
+    dw2 = torch.empty(st.T, device=y.device, dtype=torch.float32) if st.k == 2 else None
+    call("lmod_moe_combine_bwd", ptr(dout), ptr(y), ptr(st.slot1), ptr(st.slot2), ptr(st.slot_token), ptr(st.slot_w),
+         ptr(dy), ptr(dw1), ptr(dw2), st.T, S, H)
+    return dy, dw1, dw2
+
+
+def moe_gate_bwd(st, dw1, dw2, d_laux):
+    dlogits = torch.empty((st.T, st.E), device=dw1.device, dtype=torch.float32)
+    call("lmod_moe_gate_bwd", ptr(st.gates), ptr(st.idx1), ptr(st.idx2), ptr(st.slot1), ptr(st.slot2), ptr(dw1),
+         ptr(dw2), ptr(st.exp_counts), ptr(d_laux), ptr(dlogits), st.T, st.E, st.k)
+    return dlogits
+
+
+def moe_dispatch_bwd(d_in, st, dlogits, wg, H):
+    dx = torch.empty((st.T, H), device=d_in.device, dtype=BF16)
+    call("lmod_moe_dispatch_bwd", ptr(d_in), ptr(st.slot1), ptr(st.slot2), ptr(dlogits), ptr(wg), ptr(dx), st.T, H,
+         st.E)
+    return dx
+
+
+def moe_router_wgrad(x, dlogits, dwg, accumulate):
+    T, H = x.shape
+    E = dlogits.shape[1]
+    ws = torch.empty(((T + 255) // 256) * E * H, device=x.device, dtype=torch.float32)
+    call("lmod_moe_router_wgrad", ptr(x), ptr(dlogits), ptr(dwg), ptr(ws), T, H, E, int(accumulate))
+    return dwg
+
+
+# ------------------------------------------------------------------------------------------ losses
+NSTAT = 8
+
+
+def rowloss_fwd(s, Vs, t=None, Va=None, label=None):
+    R = s.shape[0]
+    stats = torch.empty((R, NSTAT), device=s.device, dtype=torch.float32)
+    if Va is None:
+        Va = Vs
+    call("lmod_rowloss_fwd", ptr(s), s.stride(0), Vs, ptr(t), t.stride(0) if t is not None else 0, Va, ptr(label),
+         ptr(stats), R)
+    return stats
+
+
+def rowloss_bwd(s, Vs, t, Va, label, stats, kd_w, ce_w, seg_id, kd_scale, ce_scale, ds=None):
+    R = s.shape[0]
+    if ds is None:
+        ds = s                      # in place over the student logits
+    call("lmod_rowloss_bwd", ptr(s), s.stride(0), Vs, ptr(t), t.stride(0) if t is not None else 0, Va, ptr(label),
+         ptr(stats), ptr(kd_w), ptr(ce_w), ptr(seg_id), ptr(kd_scale), ptr(ce_scale), ptr(ds), ds.stride(0), R)
+    return ds
+
+
+def segment_wsum(stats, col, w, seg_off):
+    nseg = seg_off.numel() - 1
+    out = torch.empty(nseg, device=stats.device, dtype=torch.float32)
+    outw = torch.empty(nseg, device=stats.device, dtype=torch.float32)
+    call("lmod_segment_wsum", ptr(stats), stats.stride(0), col, ptr(w), ptr(seg_off), nseg, ptr(out), ptr(outw))
+    return out, outw
+
+
+LOSS_TYPES = {"sigmoid": 0, "hinge": 1, "ipo": 2, "kto_pair": 3}
+
+
+def dpo_loss(pc, pr, rc, rr, beta, label_smoothing, loss_type):
+    B = pc.numel()
+    lt = LOSS_TYPES[loss_type]
+    dev = pc.device
+    losses = torch.empty(2 * B if lt == 3 else B, device=dev, dtype=torch.float32)
+    cr = torch.empty(B, device=dev, dtype=torch.float32)
+    rj = torch.empty(B, device=dev, dtype=torch.float32)
+    dpc = torch.empty(B, device=dev, dtype=torch.float32)
+    dpr = torch.empty(B, device=dev, dtype=torch.float32)
+    call("lmod_dpo_loss", ptr(pc), ptr(pr), ptr(rc), ptr(rr), B, float(beta), float(label_smoothing), lt, ptr(losses),
+         ptr(cr), ptr(rj), ptr(dpc), ptr(dpr))
+    return losses, cr, rj, dpc, dpr

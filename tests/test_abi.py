@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports exactly what include/lmod_hip.h declares (no compute, no GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "lmod_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\bint\s+(lmod_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, params = m.group(1), m.group(2)
+        sig = ""
+        for p in params.split(","):
+            p = p.strip()
+            if "hipStream_t" in p or "*" in p:
+                sig += "p"
+            elif p.startswith("long long"):
+                sig += "q"
+            elif p.startswith("float"):
+                sig += "f"
+            elif p.startswith("int"):
+                sig += "i"
+            else:
+                raise AssertionError(f"unparsed parameter {p!r} in {name}")
+        decls[name] = sig
+    return decls
+
+
+def test_header_matches_binding_table():
+    from llavamod import _hip
+    decls = _header_decls()
+    assert set(decls) == set(_hip.SIGNATURES), set(decls) ^ set(_hip.SIGNATURES)
+    for name, sig in decls.items():
+        assert sig == _hip.SIGNATURES[name], f"{name}: header {sig} != binding {_hip.SIGNATURES[name]}"
+
+
+def test_library_exports_every_declared_symbol():
+    from llavamod import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _hip.load()
+    for name in _header_decls():
+        assert hasattr(lib, name), name
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from llavamod import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _hip.load()

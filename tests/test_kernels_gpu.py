@@ -1,0 +1,464 @@
+"""Kernel-level numerics on a real MI355X: each hand-written HIP kernel (called through the C ABI)
+against a plain PyTorch fp32 reference of the same op computed from the same bf16-rounded inputs.
+Tolerances are stated per test: bf16 outputs are allowed 2 bf16 ulp (2^-7 relative) plus a small
+absolute term; fp32 outputs 1e-4..1e-3 relative (summation order differs)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from llavamod import kernels as K  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import moe as omoe  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF))
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+def close(out, ref, name, rtol=2 ** -7, afrac=2 ** -8):
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, f"{name}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    err = (out - ref).abs()
+    bound = afrac * ref.abs().max().clamp_min(1e-30) + rtol * ref.abs()
+    bad = err > bound
+    if bad.any():
+        i = torch.argmax(err - bound)
+        idx = tuple(int(x) for x in torch.unravel_index(i, err.shape))
+        raise AssertionError(f"{name}: {int(bad.sum())}/{err.numel()} outside tolerance; worst at {idx}: "
+                             f"out={out[idx].item():.6g} ref={ref[idx].item():.6g} max_abs_err={err.max().item():.4g} "
+                             f"ref_absmax={ref.abs().max().item():.4g}")
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def test_gemm_layout_identity_asymmetric():
+    # A = I (so C[m, n] must equal B[n, m]); B asymmetric -> detects transposed / permuted C writes.
+    M = N = K = 128
+    a = torch.eye(M, K, device=DEV, dtype=BF)
+    b = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 - 125).to(BF)
+    c = K_gemm(a, b)
+    close(c, b.float().t(), "gemm identity", rtol=0, afrac=0)
+
+
+def K_gemm(a, b, **kw):
+    return K.gemm_nt(a, b, **kw)
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 384, 512), (100, 200, 72), (1, 16, 8), (300, 136, 2048),
+                                     (513, 1000, 1032)])
+def test_gemm_random_shapes(M, N, K_):
+    a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2)
+    c = K_gemm(a, b)
+    close(c, a.float() @ b.float().t(), f"gemm {M}x{N}x{K_}")
+
+
+def test_gemm_bias_act_f32_accumulate():
+    M, N, K_ = 200, 264, 320
+    a, b, bias = rnd(M, K_, seed=3), rnd(N, K_, seed=4), rnd(N, seed=5)
+    ref = a.float() @ b.float().t() + bias.float()
+    close(K_gemm(a, b, bias=bias), ref, "gemm+bias")
+    pre = ref.to(BF).float()
+    close(K_gemm(a, b, bias=bias, act=1), F.gelu(pre), "gemm+bias+gelu")
+    close(K_gemm(a, b, bias=bias, act=2), pre * torch.sigmoid(1.702 * pre), "gemm+bias+quickgelu")
+    c32 = K_gemm(a, b, out_f32=True)
+    close(c32, a.float() @ b.float().t(), "gemm f32 out", rtol=1e-4, afrac=1e-5)
+    acc = torch.full((M, N), 2.0, device=DEV, dtype=torch.float32)
+    K_gemm(a, b, out=acc, out_f32=True, accumulate=True)
+    close(acc, a.float() @ b.float().t() + 2.0, "gemm f32 accumulate", rtol=1e-4, afrac=1e-5)
+
+
+def test_gemm_strided_output_and_subview():
+    # write into a column slice of a wider buffer (QKV / gate-up fusion pattern)
+    M, N, K_ = 130, 96, 128
+    a, b = rnd(M, K_, seed=6), rnd(N, K_, seed=7)
+    wide = torch.zeros((M, 3 * N), device=DEV, dtype=BF)
+    K.gemm_nt(a, b, out=wide[:, N:2 * N], M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=3 * N)
+    close(wide[:, N:2 * N], a.float() @ b.float().t(), "gemm strided out")
+    assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
+
+
+def test_gemm_grouped_valid_rows():
+    E, C, H, I = 4, 192, 128, 256
+    x = rnd(E, C, H, seed=8)
+    w = rnd(E, I, H, seed=9)
+    mv = torch.tensor([192, 0, 77, 130], device=DEV, dtype=torch.int32)
+    out = torch.zeros((E, C, I), device=DEV, dtype=BF)
+    K.gemm_nt(x, w, out=out, m_valid=mv)
+    for e in range(E):
+        n = int(mv[e])
+        if n:
+            close(out[e, :n], x[e, :n].float() @ w[e].float().t(), f"grouped e{e}")
+        assert out[e, n:].abs().max() == 0, "rows past m_valid must not be written"
+    # k_valid: reduction extent per batch (wgrad over capacity slots)
+    xt, dyt = rnd(E, H, C, seed=10), rnd(E, I, C, seed=11)
+    kv = torch.tensor([192, 0, 77, 130], device=DEV, dtype=torch.int32)
+    dw = K.gemm_nt(dyt, xt, k_valid=kv, out_f32=True)
+    for e in range(E):
+        n = (int(kv[e]) + 7) // 8 * 8     # k_valid is honoured at 8-element chunk granularity
+        ref = dyt[e, :, :n].float() @ xt[e, :, :n].float().t()
+        close(dw[e], ref, f"k_valid e{e}", rtol=1e-4, afrac=1e-5)
+
+
+def test_transpose():
+    for (R, C) in [(64, 64), (100, 72), (7, 8), (513, 1032)]:
+        x = rnd(R, C, seed=R)
+        t = K.transpose(x)
+        Rp = (R + 7) // 8 * 8
+        assert t.shape == (C, Rp)
+        close(t[:, :R], x.t(), f"transpose {R}x{C}", rtol=0, afrac=0)
+        assert t[:, R:].abs().max().item() == 0 if Rp > R else True
+    xb = rnd(3, 50, 40, seed=77)
+    tb = K.transpose(xb)
+    close(tb[:, :, :50], xb.transpose(1, 2), "batched transpose", rtol=0, afrac=0)
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("T,H", [(5, 64), (33, 2048), (16, 4096), (3, 1024)])
+def test_rmsnorm_fwd_bwd(T, H):
+    x, res, w = rnd(T, H, seed=1), rnd(T, H, seed=2), (1 + 0.1 * torch.randn(H)).to(BF).to(DEV)
+    eps = 1e-6
+    y, rstd, h = K.rmsnorm_fwd(x, w, eps, res=res)
+    hr = (x.float() + res.float()).to(BF)
+    close(h, hr, "add", rtol=0, afrac=0)
+    hf = hr.float()
+    var = hf.pow(2).mean(-1, keepdim=True)
+    yr = w.float() * (hf * torch.rsqrt(var + eps)).to(BF).float()
+    close(y, yr, "rmsnorm fwd")
+    close(rstd, torch.rsqrt(var + eps).squeeze(-1), "rstd", rtol=1e-5, afrac=1e-6)
+    y2, _, h2 = K.rmsnorm_fwd(x, w, eps)
+    assert h2 is x
+    # backward vs autograd of the fp32 op
+    dy, dres = rnd(T, H, seed=3), rnd(T, H, seed=4)
+    hh = hr.float().requires_grad_(True)
+    out = w.float() * (hh * torch.rsqrt(hh.pow(2).mean(-1, keepdim=True) + eps))
+    out.backward(dy.float())
+    dh = K.rmsnorm_bwd(dy, hr, w, rstd, dres=dres)
+    close(dh, hh.grad + dres.float(), "rmsnorm bwd", rtol=2 ** -6, afrac=2 ** -7)
+
+
+def test_layernorm_fwd():
+    T, H = 37, 1024
+    x, w, b = rnd(T, H, seed=1), rnd(H, seed=2), rnd(H, seed=3)
+    y = K.layernorm_fwd(x, w, b, 1e-5)
+    close(y, F.layer_norm(x.float(), (H,), w.float(), b.float(), 1e-5), "layernorm")
+
+
+def _rope_tables(maxpos, hd, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(maxpos).float(), inv)
+    emb = torch.cat((fr, fr), dim=-1)
+    return emb.cos().to(BF).to(DEV), emb.sin().to(BF).to(DEV)
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def test_rope_fwd_bwd():
+    T, nh, nkv, hd = 50, 4, 2, 128
+    ld = (nh + 2 * nkv) * hd
+    qkv = rnd(T, ld, seed=1)
+    cos, sin = _rope_tables(64, hd)
+    pos = (torch.arange(T) % 37).to(torch.int32).to(DEV)
+    ref = qkv.clone()
+    x = qkv[:, :(nh + nkv) * hd].reshape(T, nh + nkv, hd)
+    c, s = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+    emb = (x * c) + (_rot_half(x) * s)            # bf16 arithmetic, like the reference
+    ref[:, :(nh + nkv) * hd] = emb.reshape(T, -1)
+    out = qkv.clone()
+    K.rope_(out, cos, sin, pos, nh + nkv, hd)
+    close(out, ref, "rope fwd", rtol=2 ** -8, afrac=2 ** -9)
+    # backward = transpose map: <rope(x), g> == <x, rope_bwd(g)>
+    g = rnd(T, ld, seed=2)
+    gb = g.clone()
+    K.rope_(gb, cos, sin, pos, nh + nkv, hd, backward=True)
+    xf = x.float().requires_grad_(True)
+    yy = xf * c.float() + _rot_half(xf) * s.float()
+    yy.backward(g[:, :(nh + nkv) * hd].reshape(T, nh + nkv, hd).float())
+    close(gb[:, :(nh + nkv) * hd], xf.grad.reshape(T, -1), "rope bwd", rtol=2 ** -6, afrac=2 ** -7)
+    close(gb[:, (nh + nkv) * hd:], g[:, (nh + nkv) * hd:], "rope bwd leaves V", rtol=0, afrac=0)
+
+
+def test_swiglu_gelu_add():
+    T, I = 77, 5504
+    gu = rnd(T, 2 * I, seed=1)
+    gate, up = gu[:, :I], gu[:, I:]
+    out = K.swiglu_fwd(gate, up)
+    ref = (F.silu(gate.float()).to(BF).float() * up.float())
+    close(out, ref, "swiglu fwd")
+    d = rnd(T, I, seed=2)
+    gf, uf = gate.float().requires_grad_(True), up.float().requires_grad_(True)
+    (F.silu(gf) * uf).backward(d.float())
+    dg, du = K.swiglu_bwd(d, gate, up)
+    close(dg, gf.grad, "swiglu dgate", rtol=2 ** -6, afrac=2 ** -8)
+    close(du, uf.grad, "swiglu dup", rtol=2 ** -6, afrac=2 ** -8)
+    x = rnd(64, 2048, seed=3)
+    close(K.gelu_fwd(x), F.gelu(x.float()), "gelu fwd")
+    xf = x.float().requires_grad_(True)
+    dy = rnd(64, 2048, seed=4)
+    F.gelu(xf).backward(dy.float())
+    close(K.gelu_bwd(dy, x), xf.grad, "gelu bwd", rtol=2 ** -6, afrac=2 ** -8)
+    a, b = rnd(9, 2048, seed=5), rnd(9, 2048, seed=6)
+    close(K.add(a, b), (a.float() + b.float()).to(BF), "add", rtol=0, afrac=0)
+
+
+def test_gather_im2col_vitembed_adamw():
+    H = 256
+    ta, tb = rnd(50, H, seed=1), rnd(20, H, seed=2)
+    idx = torch.tensor([3, -1, -2, 49, -21, 0, -5], dtype=torch.int32, device=DEV)
+    out = K.gather_rows(ta, tb, idx, H)
+    ref = torch.stack([ta[3], torch.zeros(H, device=DEV, dtype=BF), tb[0], ta[49], tb[19], ta[0], tb[3]])
+    close(out, ref, "gather", rtol=0, afrac=0)
+    B, S, P = 2, 28, 14
+    pix = rnd(B, 3, S, S, seed=3)
+    kp = 592
+    cols = K.im2col_patch(pix, P, kp)
+    ref = F.unfold(pix.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(B * 4, 3 * P * P)
+    close(cols[:, :588], ref, "im2col", rtol=0, afrac=0)
+    assert cols[:, 588:].abs().max() == 0
+    D, NP = 64, 4
+    pe, cls, pos = rnd(B * NP, D, seed=4), rnd(D, seed=5), rnd(NP + 1, D, seed=6)
+    tok = K.vit_embed(pe, cls, pos, B, NP).reshape(B, NP + 1, D)
+    ref = torch.cat([cls.float().expand(B, 1, D), pe.float().reshape(B, NP, D)], 1) + pos.float()
+    close(tok, ref.to(BF), "vit_embed", rtol=0, afrac=0)
+    n = 1000
+    p0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    master, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = p0.to(BF)
+    for step in (1, 2, 3):
+        ref_p.grad = g.clone()
+        opt.step()
+        K.adamw_step(master, pb, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.1, step)
+    close(master, ref_p.detach(), "adamw", rtol=1e-5, afrac=1e-6)
+    close(pb, master.to(BF), "adamw bf16 copy", rtol=0, afrac=0)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, scale, causal, seqlens):
+    # q [B,S,nh,hd], k/v [B,S,nkv,hd] fp32
+    B, S, nh, hd = q.shape
+    nkv = k.shape[2]
+    rep = nh // nkv
+    kk = k.repeat_interleave(rep, dim=2)
+    vv = v.repeat_interleave(rep, dim=2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, kk) * scale
+    mask = torch.zeros(B, 1, S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        mask |= torch.triu(torch.ones(S, S, dtype=torch.bool, device=q.device), 1)[None, None]
+    if seqlens is not None:
+        mask |= (torch.arange(S, device=q.device)[None, :] >= seqlens[:, None].long())[:, None, None, :]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,S,nh,nkv,hd,causal,ragged", [
+    (2, 256, 4, 4, 128, True, False),
+    (2, 200, 4, 2, 128, True, True),
+    (1, 577, 4, 4, 64, False, False),
+    (2, 96, 2, 2, 64, True, True),
+    (1, 2048, 2, 2, 128, True, False),
+])
+def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
+    ld = (nh + 2 * nkv) * hd
+    qkv = rnd(B * S, ld, seed=S, scale=1.0)
+    q2, k2, v2 = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    seqlens = None
+    if ragged:
+        seqlens = torch.tensor([S - 17, max(1, S // 3)][:B], dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    o, lse = K.attn_fwd(q2, k2, v2, B, S, nh, nkv, hd, scale, causal, seqlens)
+    qf = q2.float().reshape(B, S, nh, hd).requires_grad_(True)
+    kf = k2.float().reshape(B, S, nkv, hd).requires_grad_(True)
+    vf = v2.float().reshape(B, S, nkv, hd).requires_grad_(True)
+    oref, lref = _attn_ref(qf, kf, vf, scale, causal, seqlens)
+    close(o.reshape(B, S, nh, hd), oref, "attn fwd", rtol=2 ** -6, afrac=2 ** -7)
+    close(lse, lref, "attn lse", rtol=1e-3, afrac=1e-3)
+    do = rnd(B * S, nh * hd, seed=S + 1)
+    oref.backward(do.float().reshape(B, S, nh, hd))
+    dqkv = torch.zeros_like(qkv)
+    K.attn_bwd(q2, k2, v2, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
+               dqkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, scale, causal, seqlens)
+    # the kernel recomputes P from bf16 O / lse and rounds dS to bf16: allow 2^-5 of the tensor's scale
+    close(dqkv[:, :nh * hd].reshape(B, S, nh, hd), qf.grad, "attn dQ", rtol=2 ** -5, afrac=2 ** -6)
+    close(dqkv[:, nh * hd:(nh + nkv) * hd].reshape(B, S, nkv, hd), kf.grad, "attn dK", rtol=2 ** -5, afrac=2 ** -6)
+    close(dqkv[:, (nh + nkv) * hd:].reshape(B, S, nkv, hd), vf.grad, "attn dV", rtol=2 ** -5, afrac=2 ** -6)
+
+
+def test_attn_online_softmax_rescale_branch():
+    # force a late, large max: one key far down the sequence dominates one query row (guide rule 26)
+    B, S, nh, hd = 1, 512, 1, 128
+    q = rnd(B * S, hd, seed=1, scale=0.3)
+    k = rnd(B * S, hd, seed=2, scale=0.3)
+    v = rnd(B * S, hd, seed=3)
+    k[400] = (q[450].float() * 40).to(BF)
+    o, lse = K.attn_fwd(q, k, v, B, S, nh, nh, hd, 1 / math.sqrt(hd), True)
+    oref, lref = _attn_ref(q.float().reshape(B, S, nh, hd), k.float().reshape(B, S, nh, hd),
+                           v.float().reshape(B, S, nh, hd), 1 / math.sqrt(hd), True, None)
+    close(o.reshape(B, S, nh, hd), oref, "attn spike", rtol=2 ** -6, afrac=2 ** -7)
+    close(lse, lref, "attn spike lse", rtol=1e-3, afrac=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ MoE
+@pytest.mark.parametrize("T,E,cf,noise", [(64, 4, 1.5, False), (1000, 4, 1.5, True), (777, 8, 1.0, True),
+                                          (2048, 4, 0.5, True)])
+def test_moe_gate_top2_matches_deepspeed_restatement(T, E, cf, noise):
+    H = 128
+    x = rnd(T, H, seed=T)
+    wg = (torch.randn(E, H) * 0.5).to(DEV)
+    logits = K.moe_router_fwd(x, wg)
+    close(logits, x.float() @ wg.t(), "router logits", rtol=1e-4, afrac=1e-5)
+    nz = omoe.gumbel_noise((T, E), torch.Generator().manual_seed(2)).to(DEV) if noise else None
+    C = omoe.capacity(T, E, cf * 2, 0)
+    st = K.moe_gate(logits, 2, C, nz)
+    l_aux, combine, dispatch, cnt = omoe.top2gating(logits, cf, 0, nz)
+    assert combine.shape[2] == C
+    close(st.l_aux[0], l_aux, "l_aux", rtol=1e-4, afrac=1e-6)
+    assert torch.equal(st.exp_counts.long(), cnt.long())
+    # rebuild the dense [S,E,C] combine tensor from the index maps
+    dense = torch.zeros(T, E * C, device=DEV)
+    for slot, w in ((st.slot1, st.w1), (st.slot2, st.w2)):
+        keep = slot >= 0
+        dense[torch.nonzero(keep).squeeze(1), slot[keep].long()] = w[keep]
+    close(dense.reshape(T, E, C), combine, "combine weights", rtol=1e-5, afrac=1e-6)
+    # slot_token is the inverse map
+    live = st.slot_token >= 0
+    assert int(live.sum()) == int(dispatch.sum())
+    tok = st.slot_token[live].long()
+    sl = torch.nonzero(live).squeeze(1)
+    assert torch.all((st.slot1[tok].long() == sl) | (st.slot2[tok].long() == sl))
+
+
+def test_moe_combine_dispatch_and_backward():
+    T, E, H, cf = 300, 4, 256, 1.0
+    x = rnd(T, H, seed=1)
+    wg = (torch.randn(E, H) * 0.5).to(DEV)
+    logits = K.moe_router_fwd(x, wg)
+    C = omoe.capacity(T, E, cf * 2, 0)
+    st = K.moe_gate(logits, 2, C, None)
+    disp = K.gather_rows(x, None, st.slot_token, H)                 # [E*C, H]
+    _, combine, dispatch, _ = omoe.top2gating(logits, cf, 0, None)
+    ref_disp = torch.einsum("sec,sm->ecm", dispatch.float(), x.float()).reshape(E * C, H)
+    close(disp, ref_disp, "dispatch", rtol=0, afrac=0)
+    y = rnd(E * C, H, seed=2)
+    out = K.moe_combine_fwd(y, st, H)
+    ref = torch.einsum("sec,ecm->sm", combine.to(BF).float(), y.float().reshape(E, C, H))
+    close(out, ref, "combine fwd")
+    # backward pieces vs autograd of the dense formulation
+    dout = rnd(T, H, seed=3)
+    lg = logits.clone().requires_grad_(True)
+    yf = y.float().requires_grad_(True)
+    l_aux, comb, _, _ = omoe.top2gating(lg, cf, 0, None)
+    o = torch.einsum("sec,ecm->sm", comb, yf.reshape(E, C, H))
+    (o * dout.float()).sum().backward(retain_graph=True)
+    g_main = lg.grad.clone()
+    lg.grad = None
+    (l_aux * 3.0).backward()
+    g_aux = lg.grad.clone()
+    dy, dw1, dw2 = K.moe_combine_bwd(dout, y, st, H)
+    close(dy, yf.grad, "combine dy", rtol=2 ** -6, afrac=2 ** -7)
+    dla = torch.tensor([3.0], device=DEV)
+    dlog = K.moe_gate_bwd(st, dw1, dw2, dla)
+    close(dlog, g_main + g_aux, "gate dlogits", rtol=2e-3, afrac=2e-3)
+    # router wgrad / dispatch bwd
+    dwg = torch.zeros(E, H, device=DEV)
+    K.moe_router_wgrad(x, dlog, dwg, False)
+    close(dwg, dlog.t() @ x.float(), "router wgrad", rtol=1e-4, afrac=1e-5)
+    d_in = rnd(E * C, H, seed=4)
+    dx = K.moe_dispatch_bwd(d_in, st, dlog, wg, H)
+    ref_dx = torch.einsum("sec,ecm->sm", dispatch.float(), d_in.float().reshape(E, C, H)) + (dlog @ wg).to(BF).float()
+    close(dx, ref_dx, "dispatch bwd")
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_rowloss_fwd_bwd():
+    R, Vs, Vt, Va = 9, 1024, 1152, 1000 // 8 * 8
+    s = rnd(R, Vs, seed=1, scale=2.0)
+    t = rnd(R, Vt, seed=2, scale=2.0)
+    s[0, 5] = float("-inf")                        # exercises the isinf(logp) mask
+    label = torch.tensor([3, -100, 1023, 7, -100, 0, 999, 1000, 12], dtype=torch.int32, device=DEV)
+    st = K.rowloss_fwd(s, Vs, t, Va, label)
+    sf, tf = s.float(), t.float()
+    logp = F.log_softmax(sf[:, :Va], -1)
+    p = F.softmax(tf[:, :Va], -1)
+    x = torch.where(torch.isinf(logp), torch.zeros_like(logp), p * logp).sum(-1)
+    close(st[:, 3], x, "x_kd", rtol=2e-4, afrac=1e-5)
+    lse_full = torch.logsumexp(sf, -1)
+    close(st[:, 0], lse_full, "lse full", rtol=1e-5, afrac=1e-6)
+    close(st[:, 1], torch.logsumexp(sf[:, :Va], -1), "lse align", rtol=1e-5, afrac=1e-6)
+    close(st[:, 2], torch.logsumexp(tf[:, :Va], -1), "lse teacher", rtol=1e-5, afrac=1e-6)
+    valid = label >= 0
+    ce = torch.zeros(R, device=DEV)
+    ce[valid] = lse_full[valid] - sf[valid, label[valid].long()]
+    close(st[:, 4], ce, "ce", rtol=1e-4, afrac=1e-5)
+    # backward on finite logits
+    s2 = rnd(R, Vs, seed=3, scale=2.0)
+    st2 = K.rowloss_fwd(s2, Vs, t, Va, label)
+    kd_w = torch.tensor([1, 1, 0, 1, 0, 1, 1, 0, 1], dtype=torch.float32, device=DEV)
+    ce_w = valid.float()
+    kd_scale = torch.tensor([0.37], device=DEV)
+    ce_scale = torch.tensor([-0.21], device=DEV)
+    ds = torch.empty_like(s2)
+    K.rowloss_bwd(s2, Vs, t, Va, label, st2, kd_w, ce_w, None, kd_scale, ce_scale, ds)
+    sg = s2.float().requires_grad_(True)
+    lp = F.log_softmax(sg[:, :Va], -1)
+    xk = (p * lp).sum(-1)
+    lsf = torch.logsumexp(sg, -1)
+    cer = torch.zeros(R, device=DEV)
+    cer = torch.where(valid, lsf - sg.gather(1, label.clamp_min(0).long()[:, None]).squeeze(1), cer)
+    # d/ds of  sum_r [-kd_scale*kd_w*x  (sign: ds = ckd*(q - p) = -ckd * dx/ds)] + ce_scale*ce_w*ce
+    obj = (-(kd_scale * kd_w) * xk).sum() + ((ce_scale * ce_w) * cer).sum()
+    obj.backward()
+    close(ds, sg.grad, "rowloss bwd", rtol=2 ** -6, afrac=2 ** -8)
+
+
+def test_segment_wsum_and_dpo_loss():
+    R = 1000
+    vals = torch.randn(R, 8, device=DEV)
+    w = (torch.rand(R, device=DEV) > 0.3).float()
+    off = torch.tensor([0, 10, 10, 400, 1000], dtype=torch.int32, device=DEV)
+    s, ws = K.segment_wsum(vals, 4, w, off)
+    for b in range(4):
+        lo, hi = int(off[b]), int(off[b + 1])
+        assert abs(s[b].item() - (vals[lo:hi, 4] * w[lo:hi]).sum().item()) < 1e-3
+        assert abs(ws[b].item() - w[lo:hi].sum().item()) < 1e-4
+    # known answers captured from the reference's DPOTrainer.dpo_loss
+    pc = torch.tensor([-10.0, -12.0], device=DEV); pr = torch.tensor([-11.0, -11.0], device=DEV)
+    rc = torch.tensor([-10.5, -12.5], device=DEV); rr = torch.tensor([-10.0, -12.0], device=DEV)
+    known = {"sigmoid": [0.6210, 0.7185], "hinge": [0.85, 1.05], "ipo": [12.25, 30.25],
+             "kto_pair": [0.4875, 0.4875, 0.4626, 0.5125]}
+    for lt, exp in known.items():
+        losses, cr, rj, dpc, dpr = K.dpo_loss(pc, pr, rc, rr, 0.1, 0.0, lt)
+        assert torch.allclose(losses.cpu(), torch.tensor(exp), atol=2e-4), (lt, losses)
+        a, b = pc.clone().requires_grad_(True), pr.clone().requires_grad_(True)
+        z = (a - b) - (rc - rr)
+        if lt == "sigmoid":
+            L = -F.logsigmoid(0.1 * z)
+        elif lt == "hinge":
+            L = torch.relu(1 - 0.1 * z)
+        elif lt == "ipo":
+            L = (z - 1 / (2 * 0.1)) ** 2
+        else:
+            ckl = (a - rc).mean().clamp(min=0); rkl = (b - rr).mean().clamp(min=0)
+            L = torch.cat((1 - torch.sigmoid(0.1 * ((a - rc) - rkl)), 1 - torch.sigmoid(0.1 * (ckl - (b - rr)))), 0)
+        L.mean().backward()
+        assert torch.allclose(dpc, a.grad, atol=1e-5), (lt, dpc, a.grad)
+        assert torch.allclose(dpr, b.grad, atol=1e-5), (lt, dpr, b.grad)
+        assert torch.allclose(cr, 0.1 * (pc - rc)) and torch.allclose(rj, 0.1 * (pr - rr))
