@@ -225,8 +225,8 @@ __global__ void dpo_loss_kernel(const float* __restrict__ pc, const float* __res
       losses[i] = 1.f - s1; losses[B + i] = 1.f - s2;
       const float n = 2.f * (float)B;                      // mean over the concatenated 2B vector
       // arg1_i = (pc_i - rc_i) - rkl(pr);  arg2_i = ckl(pc) - (pr_i - rr_i)
-      float dpc = g1 + ((mc > 0.f) ? G2 / (float)B : 0.f);
-      float dpr = -g2 - ((mr > 0.f) ? G1 / (float)B : 0.f);
+      float dpc = g1 + ((mc >= 0.f) ? G2 / (float)B : 0.f);   // torch clamp(min=0) passes grad at equality
+      float dpr = -g2 - ((mr >= 0.f) ? G1 / (float)B : 0.f);
       d_pc[i] = dpc / n; d_pr[i] = dpr / n;
     }
   }

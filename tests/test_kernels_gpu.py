@@ -100,7 +100,7 @@ def test_gemm_grouped_valid_rows():
         n = int(mv[e])
         if n:
             close(out[e, :n], x[e, :n].float() @ w[e].float().t(), f"grouped e{e}")
-        assert out[e, n:].abs().max() == 0, "rows past m_valid must not be written"
+        assert n == C or out[e, n:].abs().max() == 0, "rows past m_valid must not be written"
     # k_valid: reduction extent per batch (wgrad over capacity slots)
     xt, dyt = rnd(E, H, C, seed=10), rnd(E, I, C, seed=11)
     kv = torch.tensor([192, 0, 77, 130], device=DEV, dtype=torch.int32)
