@@ -59,10 +59,13 @@ int lmod_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int
 int lmod_rope(void* buf, const void* cos_t, const void* sin_t, const int* pos, int T, int nheads, int hd, int ld,
               int backward, hipStream_t stream);
 /* Qwen2MLP activation (qwen2/modeling_qwen2.py:186-187): out = bf16(silu(gate)) * up. */
+/* seg_valid (device int[rows/seg_rows]) or NULL: rows r with r % seg_rows >= seg_valid[r / seg_rows] are not
+ * read and are written as zeros (dead MoE capacity slots stay finite). */
 int lmod_swiglu_fwd(const void* gate, const void* up, void* out, long long rows, int I, int ld_gate, int ld_up,
-                    int ld_out, hipStream_t stream);
+                    int ld_out, int seg_rows, const int* seg_valid, hipStream_t stream);
 int lmod_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, long long rows, int I,
-                    int ld_dact, int ld_gate, int ld_up, int ld_dgate, int ld_dup, hipStream_t stream);
+                    int ld_dact, int ld_gate, int ld_up, int ld_dgate, int ld_dup, int seg_rows, const int* seg_valid,
+                    hipStream_t stream);
 /* nn.GELU() of the mlp2x_gelu projector (multimodal_projector/builder.py:57-61). */
 int lmod_gelu_fwd(const void* x, void* y, long long n, hipStream_t stream);
 int lmod_gelu_bwd(const void* dy, const void* x, void* dx, long long n, hipStream_t stream);
@@ -98,10 +101,11 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
  * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32). */
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);
 /* top-k (k in {1,2}) gating with capacity C: token-order slot assignment, drops, renormalised
- * combine weights, l_aux, exp_counts.  noise: additive [T,E] noise for the 2nd choice or NULL. */
+ * combine weights, l_aux, exp_counts, slots_used[E] (live rows per capacity slab).  noise: additive [T,E]
+ * noise for the 2nd choice or NULL. */
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
-                  int* exp_counts, float* gate_sum, float* l_aux, int* scratch, hipStream_t stream);
+                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream);
 /* out[t] = bf16(w1)*y[slot1[t]] + bf16(w2)*y[slot2[t]]   (einsum 'sec,ecm->sm'). */
 int lmod_moe_combine_fwd(const void* y, const int* slot1, const int* slot2, const float* w1, const float* w2,
                          void* out, int T, int H, hipStream_t stream);
@@ -132,6 +136,12 @@ int lmod_rowloss_bwd(const void* s, long long ld_s, int Vs, const void* t, long 
 /* out_sum[b] = sum_{r in [seg_off[b], seg_off[b+1])} w[r]*val[r*stride+col]; out_w[b] = sum w[r]. */
 int lmod_segment_wsum(const float* val, int stride, int col, const float* w, const int* seg_off, int nseg,
                       float* out_sum, float* out_w, hipStream_t stream);
+/* Materialising forms of AlignTrainer.get_p / get_logp (align_trainer.py:473-475,497-499): fp32 logits ->
+ * fp32 softmax / log_softmax of the first Va columns; and the masked product-sum of compute_align_loss
+ * (:509-514).  Slow-path API parity only; training uses lmod_rowloss_*. */
+int lmod_row_softmax_f32(const float* logits, long long ld, int Va, int log_flag, float* out, int R,
+                         hipStream_t stream);
+int lmod_rowdot_masked(const float* p, const float* logp, int V, int R, float* x, hipStream_t stream);
 /* DPOTrainer.dpo_loss (dpo_trainer.py:497-562), forward + d(mean loss)/d(policy logps).
  * loss_type: 0 sigmoid, 1 hinge, 2 ipo, 3 kto_pair (losses has 2B entries). */
 int lmod_dpo_loss(const float* policy_chosen, const float* policy_rejected, const float* ref_chosen,

@@ -232,6 +232,35 @@ __global__ void dpo_loss_kernel(const float* __restrict__ pc, const float* __res
   }
 }
 
+
+// ---- materialising helpers for the reference's get_p / get_logp / compute_align_loss API (slow path) ----
+// out[r, :Va] = softmax(logits[r, :Va]) (log == 0) or log_softmax (log != 0); fp32 in, fp32 out.
+__global__ __launch_bounds__(256) void row_softmax_f32_kernel(const float* __restrict__ x, long long ld, int Va, int lg,
+                                                             float* __restrict__ out) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + row * ld;
+  float* o = out + (long long)row * Va;
+  Online on = {-INFINITY, 0.f};
+  for (int i = tid; i < Va; i += 256) on_add(on, xr[i]);
+  const Online b = block_online<4>(on, red);
+  const float lse = b.m + logf(b.z);
+  for (int i = tid; i < Va; i += 256) o[i] = lg ? (xr[i] - lse) : __expf(xr[i] - lse);
+}
+// x[r] = sum_v (isinf(logp[r,v]) ? 0 : p[r,v] * logp[r,v])      (align_trainer.py:509-514)
+__global__ __launch_bounds__(256) void rowdot_masked_kernel(const float* __restrict__ p, const float* __restrict__ lp,
+                                                           int V, float* __restrict__ x) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) {
+    const float l = lp[(long long)row * V + i];
+    if (!isinf(l)) a += p[(long long)row * V + i] * l;
+  }
+  a = block_sum<4>(a, red);
+  if (threadIdx.x == 0) x[row] = a;
+}
+
 extern "C" {
 
 int lmod_rowloss_fwd(const void* s, long long ld_s, int Vs, const void* t, long long ld_t, int Va,
@@ -275,6 +304,20 @@ int lmod_dpo_loss(const float* policy_chosen, const float* policy_rejected, cons
   hipLaunchKernelGGL(dpo_loss_kernel, dim3(1), dim3(256), 0, stream, policy_chosen, policy_rejected, ref_chosen,
                      ref_rejected, B, beta, label_smoothing, loss_type, losses, chosen_rewards, rejected_rewards,
                      d_policy_chosen, d_policy_rejected);
+  return lmod_launch_status();
+}
+
+int lmod_row_softmax_f32(const float* logits, long long ld, int Va, int log_flag, float* out, int R, hipStream_t stream) {
+  if (!logits || !out || R < 0 || Va <= 0 || ld < Va) return LMOD_EINVAL;
+  if (R == 0) return LMOD_OK;
+  hipLaunchKernelGGL(row_softmax_f32_kernel, dim3(R), dim3(256), 0, stream, logits, ld, Va, log_flag, out);
+  return lmod_launch_status();
+}
+
+int lmod_rowdot_masked(const float* p, const float* logp, int V, int R, float* x, hipStream_t stream) {
+  if (!p || !logp || !x || R < 0 || V <= 0) return LMOD_EINVAL;
+  if (R == 0) return LMOD_OK;
+  hipLaunchKernelGGL(rowdot_masked_kernel, dim3(R), dim3(256), 0, stream, p, logp, V, x);
   return lmod_launch_status();
 }
 

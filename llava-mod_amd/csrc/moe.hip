@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void moe_scan_kernel(const int* __restrict__ 
                                                        const float* __restrict__ gates, int* __restrict__ loc1,
                                                        int* __restrict__ loc2, int* __restrict__ exp_counts,
                                                        float* __restrict__ gate_sum, float* __restrict__ l_aux,
-                                                       int T, int E, int k) {
+                                                       int* __restrict__ slots_used, int T, int E, int k, int C) {
   extern __shared__ int sh[];                // [2*MAXE][1024] counts, then scratch
   int* cnt = sh;                             // cnt[(j*MAXE+e)*1024 + tid]
   float* gsum = (float*)(sh + 2 * MAXE * 1024);   // [MAXE][16] per-wave partials
@@ -177,6 +177,9 @@ __global__ __launch_bounds__(1024) void moe_scan_kernel(const int* __restrict__ 
       for (int w = 0; w < 16; ++w) s += gsum[e * 16 + w];
       gate_sum[e] = s;
       exp_counts[e] = tot1[e];
+      // capacity slots are filled densely from 0: first picks, then second picks behind them
+      const int tot2 = (k >= 2) ? __float_as_int(gsum[MAXE * 16 + MAXE + e]) : 0;
+      slots_used[e] = min(C, tot1[e] + tot2);
       la += (s / (float)T) * ((float)tot1[e] / (float)T);
     }
     // top2gating: mean(me*ce)*E*E ; top1gating: sum(me*ce)*E — both equal E * sum_e(me*ce)
@@ -418,9 +421,9 @@ int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, in
 // slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.  scratch: 2*T i32 (loc1, loc2).
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
-                  int* exp_counts, float* gate_sum, float* l_aux, int* scratch, hipStream_t stream) {
+                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream) {
   if (!logits || !gates || !idx1 || !slot1 || !w1 || !slot_token || !slot_w || !exp_counts || !gate_sum || !l_aux ||
-      !scratch || T <= 0 || E <= 0 || E > MAXE || (k != 1 && k != 2) || C <= 0) return LMOD_EINVAL;
+      !slots_used || !scratch || T <= 0 || E <= 0 || E > MAXE || (k != 1 && k != 2) || C <= 0) return LMOD_EINVAL;
   if (k == 2 && (!idx2 || !slot2 || !w2)) return LMOD_EINVAL;
   int* loc1 = scratch; int* loc2 = scratch + T;
   hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k);
@@ -431,7 +434,7 @@ int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, 
     attr_set = true;
   }
   hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), sh, stream, idx1, idx2, gates, loc1, loc2, exp_counts,
-                     gate_sum, l_aux, T, E, k);
+                     gate_sum, l_aux, slots_used, T, E, k, C);
   if (hipMemsetAsync(slot_token, 0xFF, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   if (hipMemsetAsync(slot_w, 0, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   hipLaunchKernelGGL(moe_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, loc1, loc2,

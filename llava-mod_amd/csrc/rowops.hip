@@ -207,13 +207,20 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, con
 // ------------------------------------------------------------------ SwiGLU
 __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
 
+// seg_valid != NULL: rows are grouped in segments of seg_rows (MoE capacity slabs); rows at or past
+// seg_valid[segment] are NOT read and are written as zeros (keeps dead capacity slots finite).
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up,
                                                         bf16_t* __restrict__ out, long long rows, int I,
-                                                        int ld_g, int ld_u, int ld_o) {
+                                                        int ld_g, int ld_u, int ld_o, int seg_rows,
+                                                        const int* __restrict__ seg_valid) {
   const int nch = I >> 3;
   const long long total = rows * nch;
   for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
     const long long r = id / nch; const int c = (int)(id - r * nch) * 8;
+    if (seg_valid && (int)(r % seg_rows) >= seg_valid[r / seg_rows]) {
+      *(u32x4*)(out + r * ld_o + c) = (u32x4){0u, 0u, 0u, 0u};
+      continue;
+    }
     const u32x4 g = *(const u32x4*)(gate + r * ld_g + c);
     const u32x4 u = *(const u32x4*)(up + r * ld_u + c);
     u32x4 o;
@@ -228,11 +235,17 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* gate,
                                                         const bf16_t* up, bf16_t* dgate, bf16_t* dup,
                                                         long long rows, int I, int ld_d, int ld_g, int ld_u,
-                                                        int ld_dg, int ld_du) {
+                                                        int ld_dg, int ld_du, int seg_rows,
+                                                        const int* __restrict__ seg_valid) {
   const int nch = I >> 3;
   const long long total = rows * nch;
   for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
     const long long r = id / nch; const int c = (int)(id - r * nch) * 8;
+    if (seg_valid && (int)(r % seg_rows) >= seg_valid[r / seg_rows]) {
+      *(u32x4*)(dgate + r * ld_dg + c) = (u32x4){0u, 0u, 0u, 0u};
+      *(u32x4*)(dup + r * ld_du + c) = (u32x4){0u, 0u, 0u, 0u};
+      continue;
+    }
     const u32x4 d = *(const u32x4*)(dact + r * ld_d + c);
     const u32x4 g = *(const u32x4*)(gate + r * ld_g + c);
     const u32x4 u = *(const u32x4*)(up + r * ld_u + c);
@@ -434,23 +447,24 @@ int lmod_rope(void* buf, const void* cos_t, const void* sin_t, const int* pos, i
 }
 
 int lmod_swiglu_fwd(const void* gate, const void* up, void* out, long long rows, int I, int ld_gate, int ld_up,
-                    int ld_out, hipStream_t stream) {
-  if (!gate || !up || !out || rows < 0 || I <= 0 || (I & 7) || (ld_gate & 7) || (ld_up & 7) || (ld_out & 7))
-    return LMOD_EINVAL;
+                    int ld_out, int seg_rows, const int* seg_valid, hipStream_t stream) {
+  if (!gate || !up || !out || rows < 0 || I <= 0 || (I & 7) || (ld_gate & 7) || (ld_up & 7) || (ld_out & 7) ||
+      (seg_valid && seg_rows <= 0)) return LMOD_EINVAL;
   if (rows == 0) return LMOD_OK;
   hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, stream, (const bf16_t*)gate,
-                     (const bf16_t*)up, (bf16_t*)out, rows, I, ld_gate, ld_up, ld_out);
+                     (const bf16_t*)up, (bf16_t*)out, rows, I, ld_gate, ld_up, ld_out, seg_rows, seg_valid);
   return lmod_launch_status();
 }
 
 int lmod_swiglu_bwd(const void* dact, const void* gate, const void* up, void* dgate, void* dup, long long rows,
-                    int I, int ld_dact, int ld_gate, int ld_up, int ld_dgate, int ld_dup, hipStream_t stream) {
+                    int I, int ld_dact, int ld_gate, int ld_up, int ld_dgate, int ld_dup, int seg_rows,
+                    const int* seg_valid, hipStream_t stream) {
   if (!dact || !gate || !up || !dgate || !dup || rows < 0 || I <= 0 || (I & 7) || (ld_dact & 7) ||
-      (ld_gate & 7) || (ld_up & 7) || (ld_dgate & 7) || (ld_dup & 7)) return LMOD_EINVAL;
+      (ld_gate & 7) || (ld_up & 7) || (ld_dgate & 7) || (ld_dup & 7) || (seg_valid && seg_rows <= 0)) return LMOD_EINVAL;
   if (rows == 0) return LMOD_OK;
   hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I >> 3))), dim3(256), 0, stream, (const bf16_t*)dact,
                      (const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)dgate, (bf16_t*)dup, rows, I, ld_dact,
-                     ld_gate, ld_up, ld_dgate, ld_dup);
+                     ld_gate, ld_up, ld_dgate, ld_dup, seg_rows, seg_valid);
   return lmod_launch_status();
 }
 

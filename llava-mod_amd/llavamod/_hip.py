@@ -20,8 +20,8 @@ SIGNATURES = {
     "lmod_rmsnorm_bwd": "pppppp" + "ii" + "p",
     "lmod_layernorm_fwd": "pppp" + "iif" + "p",
     "lmod_rope": "pppp" + "iiiii" + "p",
-    "lmod_swiglu_fwd": "ppp" + "qiiii" + "p",
-    "lmod_swiglu_bwd": "ppppp" + "qiiiiii" + "p",
+    "lmod_swiglu_fwd": "ppp" + "qiiii" + "ip" + "p",
+    "lmod_swiglu_bwd": "ppppp" + "qiiiiii" + "ip" + "p",
     "lmod_gelu_fwd": "pp" + "q" + "p",
     "lmod_gelu_bwd": "ppp" + "q" + "p",
     "lmod_add_bf16": "ppp" + "q" + "p",
@@ -32,7 +32,7 @@ SIGNATURES = {
     "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
     "lmod_moe_router_fwd": "ppp" + "iii" + "p",
-    "lmod_moe_gate": "pp" + "iiii" + "ppppppppppppp" + "p",
+    "lmod_moe_gate": "pp" + "iiii" + "pppppppppppppp" + "p",
     "lmod_moe_combine_fwd": "pppppp" + "ii" + "p",
     "lmod_moe_combine_bwd": "ppppppppp" + "iii" + "p",
     "lmod_moe_gate_bwd": "pppppppppp" + "iii" + "p",
@@ -41,6 +41,8 @@ SIGNATURES = {
     "lmod_rowloss_fwd": "pqi" + "pqi" + "pp" + "i" + "p",
     "lmod_rowloss_bwd": "pqi" + "pqi" + "pp" + "ppppp" + "pq" + "i" + "p",
     "lmod_segment_wsum": "pii" + "pp" + "i" + "pp" + "p",
+    "lmod_row_softmax_f32": "pqii" + "pi" + "p",
+    "lmod_rowdot_masked": "pp" + "ii" + "p" + "p",
     "lmod_dpo_loss": "pppp" + "iffi" + "ppppp" + "p",
 }
 _CT = {"p": _P, "i": _I, "q": _Q, "f": _F}

@@ -1,0 +1,159 @@
+"""Step engine around the model: flat fp32 gradient buffer (wgrad GEMMs accumulate into it directly),
+data-parallel gradient exchange over RCCL, fused AdamW on fp32 masters with bf16 working weights,
+warmup-cosine LR.  This replaces what the reference gets from HF Trainer + DeepSpeed ZeRO-2
+(config/dpconfig/zero2*.json, train/align_trainer.py:326-434): only the semantics the step needs —
+mean of the trainable-parameter gradients over DP ranks once per optimizer step, AdamW — are kept;
+no CPU offload (288 GB of HBM holds teacher + student + fp32 optimizer state outright).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from .ops import FusedWeight
+
+BF16 = torch.bfloat16
+
+
+def fused_weights_of(model):
+    seen, out = set(), []
+    for m in model.modules():
+        for v in vars(m).values():
+            if isinstance(v, FusedWeight) and id(v) not in seen:
+                seen.add(id(v))
+                out.append(v)
+    return out
+
+
+class GradBuffer:
+    """One flat fp32 buffer holding every trainable parameter's gradient.  Fused weights (q/k/v,
+    gate/up, stacked experts) get one contiguous span so a single wgrad GEMM fills them."""
+
+    def __init__(self, model):
+        self.model = model
+        spans = []          # (kind, obj, numel)
+        covered = set()
+        for fw in fused_weights_of(model):
+            ps = fw.params
+            # expert copies keep a private (unused) FusedWeight of their own; the MoE layer's stacked one wins
+            if any(id(p) in covered for p in ps):
+                continue
+            if fw.requires_grad:
+                fw.ensure()
+                spans.append(("w", fw, fw.w.numel()))
+                covered.update(id(p) for p in ps)
+            if fw.bias_groups is not None:
+                bs = fw.bias_groups[0]
+                if any(b.requires_grad for b in bs):
+                    fw.ensure()
+                    spans.append(("b", fw, fw.b.numel()))
+                covered.update(id(b) for b in bs)
+        # stacked MoE weights must win over per-expert private FusedWeights: order by size desc was not
+        # needed because MoE modules are visited before their expert children in model.modules().
+        for n, p in model.named_parameters():
+            if p.requires_grad and id(p) not in covered:
+                spans.append(("p", p, p.numel()))
+                covered.add(id(p))
+        self.spans = spans
+        total = sum(n for _, _, n in spans)
+        dev = next(model.parameters()).device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self.offsets = []
+        for kind, obj, n in spans:
+            view = self.flat[off:off + n]
+            if kind == "w":
+                obj.set_grad_buffer(view.view(obj.w.shape))
+            elif kind == "b":
+                obj.set_bias_grad_buffer(view.view(obj.b.shape))
+            else:
+                obj.main_grad = view.view(obj.shape)
+            self.offsets.append(off)
+            off += n
+        self.numel = total
+
+    def zero(self):
+        self.flat.zero_()
+
+
+class DataParallel:
+    """Sample-sharded data parallelism: every rank runs teacher + student on its own micro-batches; the
+    only exchange is the SUM all-reduce of the flat gradient buffer at the optimizer boundary (the
+    division by world size is folded into AdamW's grad scale).  Loss normalisation stays per-rank, as
+    in the reference (align_trainer.py:526 divides by the local mask sum; DeepSpeed then averages)."""
+
+    def __init__(self, bucket_bytes=512 << 20):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.bucket = bucket_bytes // 4
+
+    def all_reduce(self, flat):
+        if not self.enabled:
+            return
+        handles = []
+        for lo in range(0, flat.numel(), self.bucket):
+            handles.append(dist.all_reduce(flat[lo:lo + self.bucket], op=dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+
+
+class HipAdamW:
+    """torch.optim.AdamW arithmetic (HF `adamw_torch`, reference config/args.py:78) as one fused kernel per
+    span: fp32 master / m / v, bf16 working copy refreshed in the same pass."""
+
+    def __init__(self, gb: GradBuffer, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.gb = gb
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        dev = gb.flat.device
+        self.master = torch.empty(gb.numel, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
+        self.step_count = 0
+        self._scratch = {}
+        for (kind, obj, n), off in zip(gb.spans, gb.offsets):
+            src = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
+            self.master[off:off + n].copy_(src.reshape(-1).float())
+
+    def step(self, grad_scale=1.0, lr=None):
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        for (kind, obj, n), off in zip(self.gb.spans, self.gb.offsets):
+            tgt = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
+            if tgt.dtype == BF16:
+                pb = tgt
+            else:                                   # fp32 parameter (router wg): bf16 copy goes to scratch
+                pb = self._scratch.setdefault(n, torch.empty(n, device=tgt.device, dtype=BF16))
+            K.adamw_step(self.master[off:off + n], pb, self.gb.flat[off:off + n], self.m[off:off + n],
+                         self.v[off:off + n], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                         grad_scale)
+            if tgt.dtype != BF16:
+                tgt.reshape(-1).copy_(self.master[off:off + n])
+            if kind == "w":
+                obj._wt_version = None      # the kernel wrote behind torch's back: invalidate the cached W^T
+
+
+def warmup_cosine(step, total_steps, base_lr, warmup_ratio=0.03):
+    """`--lr_scheduler_type cosine --warmup_ratio 0.03` (dense2sparse_distillation.sh:78-80)."""
+    warm = max(1, int(math.ceil(total_steps * warmup_ratio)))
+    if step < warm:
+        return base_lr * (step + 1) / warm
+    prog = (step - warm) / max(1, total_steps - warm)
+    return base_lr * 0.5 * (1.0 + math.cos(math.pi * min(1.0, prog)))
+
+
+def init_distributed():
+    """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the launcher.  backend "nccl" is RCCL."""
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(0)
+        return 0, 0, 1
+    rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
+    return rank, local, world

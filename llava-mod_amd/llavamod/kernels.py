@@ -87,22 +87,23 @@ def rope_(buf, cos_t, sin_t, pos, nheads, hd, backward=False):
     return buf
 
 
-def swiglu_fwd(gate, up, out=None):
+def swiglu_fwd(gate, up, out=None, seg_rows=0, seg_valid=None):
     rows, I = gate.shape
     if out is None:
         out = torch.empty((rows, I), device=gate.device, dtype=BF16)
-    call("lmod_swiglu_fwd", ptr(gate), ptr(up), ptr(out), rows, I, gate.stride(0), up.stride(0), out.stride(0))
+    call("lmod_swiglu_fwd", ptr(gate), ptr(up), ptr(out), rows, I, gate.stride(0), up.stride(0), out.stride(0),
+         seg_rows, ptr(seg_valid))
     return out
 
 
-def swiglu_bwd(dact, gate, up, dgate=None, dup=None):
+def swiglu_bwd(dact, gate, up, dgate=None, dup=None, seg_rows=0, seg_valid=None):
     rows, I = gate.shape
     if dgate is None:
         dgate = torch.empty((rows, I), device=gate.device, dtype=BF16)
     if dup is None:
         dup = torch.empty((rows, I), device=gate.device, dtype=BF16)
     call("lmod_swiglu_bwd", ptr(dact), ptr(gate), ptr(up), ptr(dgate), ptr(dup), rows, I, dact.stride(0),
-         gate.stride(0), up.stride(0), dgate.stride(0), dup.stride(0))
+         gate.stride(0), up.stride(0), dgate.stride(0), dup.stride(0), seg_rows, ptr(seg_valid))
     return dgate, dup
 
 
@@ -182,7 +183,7 @@ def moe_router_fwd(x, wg):
 class GateState:
     """Index maps produced by lmod_moe_gate (all device tensors)."""
     __slots__ = ("T", "E", "k", "C", "gates", "idx1", "idx2", "slot1", "slot2", "w1", "w2", "slot_token", "slot_w",
-                 "exp_counts", "gate_sum", "l_aux")
+                 "exp_counts", "gate_sum", "l_aux", "slots_used")
 
 
 def moe_gate(logits, k, C, noise=None):
@@ -200,10 +201,11 @@ def moe_gate(logits, k, C, noise=None):
         st.idx2 = st.slot2 = st.w2 = None
     st.slot_token = torch.empty(E * C, **i32); st.slot_w = torch.empty(E * C, **f32)
     st.exp_counts = torch.empty(E, **i32); st.gate_sum = torch.empty(E, **f32); st.l_aux = torch.empty(1, **f32)
+    st.slots_used = torch.empty(E, **i32)
     scratch = torch.empty(2 * T, **i32)
     call("lmod_moe_gate", ptr(logits), ptr(noise), T, E, k, C, ptr(st.gates), ptr(st.idx1), ptr(st.idx2),
          ptr(st.slot1), ptr(st.slot2), ptr(st.w1), ptr(st.w2), ptr(st.slot_token), ptr(st.slot_w),
-         ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(scratch))
+         ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(st.slots_used), ptr(scratch))
     return st
 
 
@@ -291,3 +293,18 @@ def dpo_loss(pc, pr, rc, rr, beta, label_smoothing, loss_type):
     call("lmod_dpo_loss", ptr(pc), ptr(pr), ptr(rc), ptr(rr), B, float(beta), float(label_smoothing), lt, ptr(losses),
          ptr(cr), ptr(rj), ptr(dpc), ptr(dpr))
     return losses, cr, rj, dpc, dpr
+
+
+def row_softmax_f32(logits_f32, Va, log):
+    """[R, V] fp32 -> fp32 softmax / log_softmax over the first Va columns (materialising API parity)."""
+    R = logits_f32.shape[0]
+    out = torch.empty((R, Va), device=logits_f32.device, dtype=torch.float32)
+    call("lmod_row_softmax_f32", ptr(logits_f32), logits_f32.stride(0), Va, int(log), ptr(out), R)
+    return out
+
+
+def rowdot_masked(p, logp):
+    R, V = p.shape
+    x = torch.empty(R, device=p.device, dtype=torch.float32)
+    call("lmod_rowdot_masked", ptr(p), ptr(logp), V, R, ptr(x))
+    return x

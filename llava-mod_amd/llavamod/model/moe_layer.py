@@ -1,0 +1,97 @@
+"""`MoE` — drop-in for `deepspeed.moe.layer.MoE` as the reference uses it (constructor call
+llava_qwen2_moe.py:536-546; result 3-tuple consumed at :161-167; `.deepspeed_moe.experts.deepspeed_experts`
+read at :547; router parameter name contains `wg`, matched by substring at :501-506,619-626).
+
+Semantics restate DeepSpeed 0.9.5 (top-1/top-2 gating with capacity, token-order slots, drops,
+renormalised top-2 weights, l_aux) but execute sparsely on HIP kernels: see llavamod.ops.MoEBlock.
+Expert parallelism: `ep_size` > 1 shards the experts over ranks and exchanges capacity slabs with
+an RCCL all-to-all (llavamod.engine.ExpertParallel); ep_size == 1 is the reference shells' setting.
+"""
+import copy
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import FusedWeight
+
+
+class _Gate(nn.Module):
+    def __init__(self, hidden, num_experts, device):
+        super().__init__()
+        # TopKGate keeps wg in fp32 and feeds it x.float() (sharded_moe.TopKGate.forward)
+        self.wg = nn.Linear(hidden, num_experts, bias=False, device=device, dtype=torch.float32)
+
+
+class _Experts(nn.Module):
+    def __init__(self, expert, n):
+        super().__init__()
+        self.deepspeed_experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(n)])
+        for e in self.deepspeed_experts:
+            for p in e.parameters():
+                p.allreduce = False          # deepspeed.moe.experts.Experts tags expert params this way
+                p.group_name = "ep_size_1"
+
+
+class _DSMoE(nn.Module):
+    def __init__(self, hidden, expert, num_experts, device):
+        super().__init__()
+        self.gate = _Gate(hidden, num_experts, device)
+        self.experts = _Experts(expert, num_experts)
+
+
+class MoE(nn.Module):
+    def __init__(self, hidden_size, expert, num_experts=1, ep_size=1, k=1, capacity_factor=1.0,
+                 eval_capacity_factor=1.0, min_capacity=4, use_residual=False, noisy_gate_policy=None,
+                 drop_tokens=True, use_rts=True, use_tutel=False, enable_expert_tensor_parallelism=False):
+        super().__init__()
+        if k not in (1, 2):
+            raise ValueError("Only top-1 and top-2 gatings are supported (DeepSpeed 0.9.5 TopKGate)")
+        if num_experts % ep_size:
+            raise ValueError(f"Number of experts ({num_experts}) should be divisible by expert parallel size ({ep_size})")
+        if num_experts > 8:
+            raise NotImplementedError("the routing kernels are compiled for <= 8 experts")
+        if use_residual:
+            raise NotImplementedError("use_residual (Residual-MoE) is not on the distillation hot path")
+        self.hidden_size, self.num_experts, self.ep_size, self.k = hidden_size, num_experts, ep_size, k
+        self.capacity_factor, self.eval_capacity_factor, self.min_capacity = capacity_factor, eval_capacity_factor, min_capacity
+        self.use_rts = use_rts
+        device = next(expert.parameters()).device
+        self.deepspeed_moe = _DSMoE(hidden_size, expert, num_experts, device)
+        ex = self.deepspeed_moe.experts.deepspeed_experts
+        self._gu = FusedWeight([[e.gate_proj.weight, e.up_proj.weight] for e in ex])
+        self._down = FusedWeight([[e.down_proj.weight] for e in ex])
+        self.gate_noise = None     # explicit [T, E] Gumbel noise for the next top-2 forward (None: sampled)
+        self.deterministic = False  # True: no noise at all (parity tests)
+
+    def capacity(self, T):
+        cf = self.capacity_factor if self.training else self.eval_capacity_factor
+        if self.k == 2:
+            cf = cf * 2
+        return max(int(math.ceil((T / self.num_experts) * cf)), int(self.min_capacity), 1)
+
+    def fused_weights(self):
+        return [self._gu, self._down]
+
+    def trainable(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def forward(self, hidden_states, rt=None):
+        shp = hidden_states.shape
+        x = hidden_states.reshape(-1, shp[-1])
+        T = x.shape[0]
+        wg = self.deepspeed_moe.gate.wg.weight
+        noise = None
+        if self.k == 2 and not self.deterministic:
+            if self.gate_noise is not None:
+                noise = self.gate_noise.to(device=x.device, dtype=torch.float32).contiguous()
+            else:   # gumbel_rsample of sharded_moe.top2gating
+                u = torch.rand((T, self.num_experts), device=x.device).clamp_(1e-20, 1.0)
+                noise = -torch.log(-torch.log(u))
+        spec = SimpleNamespace(E=self.num_experts, k=self.k, capacity=self.capacity, wg=wg,
+                               gu=self._gu.ensure(), down=self._down.ensure())
+        out, l_aux, counts = ops.MoEBlock.apply(x, spec, noise, *self.trainable())
+        self.last_state = spec.last_state          # routing maps of this call (inspection / tests)
+        return out.reshape(shp), l_aux.reshape(()), counts

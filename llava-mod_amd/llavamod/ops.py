@@ -1,0 +1,435 @@
+"""Autograd shim: fused blocks of the decoder expressed as torch.autograd.Functions whose forward and
+backward are sequences of C-ABI kernel launches (llavamod.kernels).  torch supplies the tape, device
+memory and the stream — no torch math runs on [T,H]-sized data here.
+
+Weight-gradient convention: trainable weights own an fp32 `main_grad` tensor (views into one flat
+buffer, see llavamod.engine.GradBuffer); wgrad GEMMs accumulate straight into it from the GEMM
+epilogue and the Function returns None for that input.  That is the layout the RCCL gradient
+exchange and the fused AdamW consume.
+"""
+import torch
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------ weights
+class FusedWeight:
+    """A [N, K] bf16 weight matrix — possibly the row-concatenation of several nn.Parameters (q/k/v,
+    gate/up), or with a leading expert dim [E, N, K] — plus the K-contiguous transpose that the dgrad
+    GEMM needs (refreshed when the parameters' version counters change, i.e. after an optimizer
+    step) and an fp32 main_grad of the same shape.  The nn.Parameters are re-pointed at slices of
+    the fused storage, so state_dict names/shapes stay the reference's."""
+
+    def __init__(self, groups, bias_groups=None):
+        # groups: list over experts (len 1 for a plain weight) of lists of params concatenated by rows
+        self.groups = [list(g) for g in groups]
+        self.bias_groups = [list(g) for g in bias_groups] if bias_groups is not None else None
+        self.stacked = len(self.groups) > 1
+        self.w = self.b = self.wt = None
+        self._wt_version = None
+        self.main_grad = None
+        self.bias_main_grad = None
+
+    def __deepcopy__(self, memo):
+        # deep copies (MoE up-cycling copies the dense FFN per expert) share nothing and start unfused
+        import copy
+        groups = [[copy.deepcopy(p, memo) for p in g] for g in self.groups]
+        biases = [[copy.deepcopy(b, memo) for b in g] for g in self.bias_groups] if self.bias_groups is not None else None
+        return FusedWeight(groups, biases)
+
+    def _views(self, buf):
+        for e, g in enumerate(self.groups):
+            r = 0
+            for p in g:
+                yield p, (buf[e, r:r + p.shape[0]] if self.stacked else buf[r:r + p.shape[0]])
+                r += p.shape[0]
+
+    def ensure(self):
+        p0 = self.groups[0][0]
+        ok = self.w is not None and self.w.device == p0.device
+        if ok:
+            ok = all(p.data_ptr() == v.data_ptr() for p, v in self._views(self.w))
+        if not ok:
+            rows = sum(p.shape[0] for p in self.groups[0])
+            shape = (len(self.groups), rows, p0.shape[1]) if self.stacked else (rows, p0.shape[1])
+            w = torch.empty(shape, device=p0.device, dtype=BF16)
+            for p, v in self._views(w):
+                v.copy_(p.data)
+                p.data = v
+            self.w, self.wt, self.main_grad = w, None, None
+            if self.bias_groups is not None:
+                bs = self.bias_groups[0]
+                b = torch.empty(rows, device=p0.device, dtype=BF16)
+                r = 0
+                for bp in bs:
+                    b[r:r + bp.shape[0]].copy_(bp.data)
+                    bp.data = b[r:r + bp.shape[0]]
+                    r += bp.shape[0]
+                self.b, self.bias_main_grad = b, None
+        return self
+
+    @property
+    def params(self):
+        return [p for g in self.groups for p in g]
+
+    @property
+    def requires_grad(self):
+        return any(p.requires_grad for p in self.params)
+
+    @property
+    def bias_requires_grad(self):
+        return self.bias_groups is not None and any(b.requires_grad for b in self.bias_groups[0])
+
+    def transposed(self):
+        ver = tuple(p._version for p in self.params)
+        if self.wt is None or self._wt_version != ver:
+            self.wt = K.transpose(self.w, out=self.wt)
+            self._wt_version = ver
+        return self.wt
+
+    def grad_buffer(self):
+        if self.main_grad is None:
+            self.set_grad_buffer(torch.zeros(self.w.shape, device=self.w.device, dtype=torch.float32))
+        return self.main_grad
+
+    def set_grad_buffer(self, buf):
+        self.main_grad = buf
+        for p, v in self._views(buf):
+            p.main_grad = v
+
+    def bias_grad_buffer(self):
+        if self.bias_main_grad is None:
+            self.set_bias_grad_buffer(torch.zeros(self.b.shape, device=self.b.device, dtype=torch.float32))
+        return self.bias_main_grad
+
+    def set_bias_grad_buffer(self, buf):
+        self.bias_main_grad = buf
+        r = 0
+        for bp in self.bias_groups[0]:
+            bp.main_grad = buf[r:r + bp.shape[0]]
+            r += bp.shape[0]
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones((8, n), device=device, dtype=BF16)
+    return _ONES[key]
+
+
+def linear_fwd(x, fw, act=0, out=None):
+    """y = act(x @ W^T + b)."""
+    return K.gemm_nt(x, fw.w, bias=fw.b, act=act, out=out)
+
+
+def linear_dgrad(dy, fw):
+    """dx = dy @ W  (NT GEMM against the cached W^T [K_in, N_pad])."""
+    wt = fw.transposed()
+    return K.gemm_nt(dy, wt, M=dy.shape[0], N=wt.shape[0], K=fw.w.shape[0], lda=dy.stride(0), ldb=wt.stride(0))
+
+
+def linear_wgrad(dy, x, fw):
+    """main_grad += dy^T @ x ; bias main_grad += colsum(dy)."""
+    dyt = K.transpose(dy)                     # [N, Tpad]
+    xt = K.transpose(x)                       # [K, Tpad]
+    K.gemm_nt(dyt, xt, out=fw.grad_buffer(), out_f32=True, accumulate=True)
+    if fw.bias_requires_grad:
+        tmp = K.gemm_nt(dyt, _ones(dyt.shape[1], dy.device), out_f32=True)      # [N, 8]; every column = token sum
+        fw.bias_grad_buffer().add_(tmp[:, 0])
+
+
+# ------------------------------------------------------------------------------------------ norm
+class AddRMSNorm(torch.autograd.Function):
+    """(delta, res) -> (y, h):  h = res + delta (bf16), y = RMSNorm(h) * w.  res may be None (h = delta).
+    Qwen2RMSNorm (qwen2/modeling_qwen2.py:83-97) fused with the residual add of the decoder layer."""
+
+    @staticmethod
+    def forward(ctx, delta, res, w, eps):
+        y, rstd, h = K.rmsnorm_fwd(delta, w, eps, res=res)
+        ctx.save_for_backward(h, w, rstd)
+        ctx.has_res = res is not None
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh):
+        h, w, rstd = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(h)
+        g = K.rmsnorm_bwd(dy.contiguous(), h, w, rstd, dres=dh.contiguous() if dh is not None else None)
+        return g, (g if ctx.has_res else None), None, None
+
+
+# ------------------------------------------------------------------------------------------ attention block
+class AttnBlock(torch.autograd.Function):
+    """x[T,H] -> o_proj(attention(rope(qkv_proj(x)))).  Decoder self-attention of
+    qwen2/modeling_qwen2.py:631-715 as four launches: fused QKV GEMM(+bias), in-place RoPE,
+    flash attention, O GEMM.  `params` are the trainable tensors (only so autograd schedules backward)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        B, S, nh, nkv, hd = spec.B, spec.S, spec.nh, spec.nkv, spec.hd
+        qkv = linear_fwd(x, spec.qkv)
+        K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
+        q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        need = any(ctx.needs_input_grad)
+        o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need)
+        out = linear_fwd(o, spec.o)
+        ctx.spec = spec
+        if need:
+            ctx.save_for_backward(x if spec.qkv.requires_grad else None, qkv, o, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp = ctx.spec
+        x, qkv, o, lse = ctx.saved_tensors
+        nh, nkv, hd = sp.nh, sp.nkv, sp.hd
+        dout = dout.contiguous()
+        do = linear_dgrad(dout, sp.o)
+        if sp.o.requires_grad:
+            linear_wgrad(dout, o, sp.o)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
+                   dqkv[:, (nh + nkv) * hd:], sp.B, sp.S, nh, nkv, hd, sp.scale, True, sp.seqlens)
+        K.rope_(dqkv, sp.cos, sp.sin, sp.pos, nh + nkv, hd, backward=True)
+        dx = linear_dgrad(dqkv, sp.qkv)
+        if sp.qkv.requires_grad:
+            linear_wgrad(dqkv, x, sp.qkv)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ------------------------------------------------------------------------------------------ dense SwiGLU MLP
+class MLPBlock(torch.autograd.Function):
+    """down(silu(gate(x)) * up(x)) with gate/up as ONE [2I, H] GEMM (qwen2/modeling_qwen2.py:175-187)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        gu = linear_fwd(x, spec.gu)
+        I = spec.gu.w.shape[0] // 2
+        act = K.swiglu_fwd(gu[:, :I], gu[:, I:])
+        out = linear_fwd(act, spec.down)
+        ctx.spec = spec
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, gu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp = ctx.spec
+        x, gu = ctx.saved_tensors
+        I = sp.gu.w.shape[0] // 2
+        dout = dout.contiguous()
+        dact = linear_dgrad(dout, sp.down)
+        if sp.down.requires_grad:
+            act = K.swiglu_fwd(gu[:, :I], gu[:, I:])          # recomputed, not stored
+            linear_wgrad(dout, act, sp.down)
+            del act
+        dgu = torch.empty_like(gu)
+        K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+        dx = linear_dgrad(dgu, sp.gu)
+        if sp.gu.requires_grad:
+            linear_wgrad(dgu, x, sp.gu)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ------------------------------------------------------------------------------------------ projector
+def _drop_cls_idx(B, P1, device):
+    return (torch.arange(B, device=device)[:, None] * P1 + torch.arange(1, P1, device=device)[None]).reshape(-1).to(torch.int32)
+
+
+class ProjectorBlock(torch.autograd.Function):
+    """mlp2x_gelu: Linear + exact GELU + Linear (multimodal_projector/builder.py:57-61,148-149) applied to
+    the tower output [B, 1+P, Dv] with the CLS row of every image skipped by the batched-GEMM stride
+    (feature_select 'patch', clip_encoder.py:36-38).  Returns [B*P, H]."""
+
+    @staticmethod
+    def forward(ctx, feats, spec, *params):
+        B, P1, Dv = feats.shape
+        P = P1 - 1
+        H = spec.fc1.w.shape[0]
+        pre = torch.empty((B * P, H), device=feats.device, dtype=BF16)
+        first_patch = feats.reshape(B * P1, Dv)[1:]          # start one row in; batch stride spans the CLS row
+        K.gemm_nt(first_patch, spec.fc1.w, bias=spec.fc1.b, out=pre, M=P, N=H, K=Dv, lda=Dv, ldb=Dv, ldc=H, batch=B,
+                  strides=(P1 * Dv, 0, P * H))
+        mid = K.gelu_fwd(pre)
+        out = linear_fwd(mid, spec.fc2)
+        ctx.spec = spec
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(feats, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp = ctx.spec
+        feats, pre = ctx.saved_tensors
+        B, P1, Dv = feats.shape
+        dout = dout.contiguous()
+        dmid = linear_dgrad(dout, sp.fc2)
+        if sp.fc2.requires_grad:
+            linear_wgrad(dout, K.gelu_fwd(pre), sp.fc2)
+        dpre = K.gelu_bwd(dmid, pre)
+        if sp.fc1.requires_grad:
+            xin = K.gather_rows(feats.reshape(B * P1, Dv), None, _drop_cls_idx(B, P1, feats.device), Dv)
+            linear_wgrad(dpre, xin, sp.fc1)
+        # the vision tower is frozen and runs under no_grad (clip_encoder.py:31,45): nothing flows past here
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ------------------------------------------------------------------------------------------ splice
+class SpliceEmbed(torch.autograd.Function):
+    """inputs_embeds[B*S', H] = rows gathered from the (frozen) embedding table and the projector output
+    according to a host-built index map (llava_arch.py:236-318).  Backward routes rows to the projector."""
+
+    @staticmethod
+    def forward(ctx, img_feats, embed_w, idx, inv_idx):
+        H = embed_w.shape[1]
+        out = K.gather_rows(embed_w, img_feats, idx, H)
+        ctx.save_for_backward(inv_idx)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (inv_idx,) = ctx.saved_tensors
+        return K.gather_rows(dout.contiguous(), None, inv_idx, ctx.H), None, None, None
+
+
+# ------------------------------------------------------------------------------------------ MoE
+class MoEBlock(torch.autograd.Function):
+    """Sparse top-k MoE FFN with DeepSpeed-0.9.5 capacity semantics (deepspeed.moe.sharded_moe;
+    reference call site llava_qwen2_moe.py:536-546, result :161-167): fp32 router -> gating kernels ->
+    row gather into [E, C, H] capacity slabs -> grouped SwiGLU GEMMs (rows past each expert's live
+    count skipped) -> weighted combine.  Returns (out[T,H], l_aux[1], exp_counts[E])."""
+
+    @staticmethod
+    def forward(ctx, x, spec, noise, *params):
+        T, H = x.shape
+        E, C, k = spec.E, spec.capacity(T), spec.k
+        logits = K.moe_router_fwd(x, spec.wg.data)
+        st = K.moe_gate(logits, k, C, noise)
+        rows = st.slots_used
+        disp = K.gather_rows(x, None, st.slot_token, H)                       # [E*C, H], zero rows on empty slots
+        I = spec.gu.w.shape[1] // 2
+        gu = torch.empty((E, C, 2 * I), device=x.device, dtype=BF16)
+        K.gemm_nt(disp.view(E, C, H), spec.gu.w, out=gu, m_valid=rows)
+        gu2 = gu.view(E * C, 2 * I)
+        act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rows)
+        y = torch.empty((E, C, H), device=x.device, dtype=BF16)
+        K.gemm_nt(act.view(E, C, I), spec.down.w, out=y, m_valid=rows)
+        out = K.moe_combine_fwd(y.view(E * C, H), st, H)
+        ctx.spec, ctx.st = spec, st
+        spec.last_state = st
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, disp, gu, y)
+        l_aux, counts = st.l_aux.clone(), st.exp_counts
+        ctx.mark_non_differentiable(counts)
+        return out, l_aux, counts
+
+    @staticmethod
+    def backward(ctx, dout, dlaux, _dc):
+        sp, st = ctx.spec, ctx.st
+        x, disp, gu, y = ctx.saved_tensors
+        T, H = x.shape
+        E, C = st.E, st.C
+        I = sp.gu.w.shape[1] // 2
+        rows = st.slots_used
+        if dout is None:
+            dout = torch.zeros_like(x)
+        dy, dw1, dw2 = K.moe_combine_bwd(dout.contiguous(), y.view(E * C, H), st, H)   # dy: zero rows on empty slots
+        dact = torch.empty((E, C, I), device=x.device, dtype=BF16)
+        K.gemm_nt(dy.view(E, C, H), sp.down.transposed(), out=dact, m_valid=rows)
+        gu2 = gu.view(E * C, 2 * I)
+        if sp.down.requires_grad:
+            act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rows)
+            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act.view(E, C, I)), out=sp.down.grad_buffer(),
+                      out_f32=True, accumulate=True, k_valid=rows)
+            del act
+        dgu = torch.empty_like(gu)
+        dgu2 = dgu.view(E * C, 2 * I)
+        K.swiglu_bwd(dact.view(E * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rows)
+        d_in = torch.empty((E, C, H), device=x.device, dtype=BF16)
+        K.gemm_nt(dgu, sp.gu.transposed(), out=d_in, m_valid=rows)
+        if sp.gu.requires_grad:
+            K.gemm_nt(K.transpose(dgu), K.transpose(disp.view(E, C, H)), out=sp.gu.grad_buffer(), out_f32=True,
+                      accumulate=True, k_valid=rows)
+        dlogits = K.moe_gate_bwd(st, dw1, dw2, dlaux.contiguous().float() if dlaux is not None else None)
+        if sp.wg.requires_grad:
+            if getattr(sp.wg, "main_grad", None) is None:
+                sp.wg.main_grad = torch.zeros(sp.wg.shape, device=x.device, dtype=torch.float32)
+            K.moe_router_wgrad(x, dlogits, sp.wg.main_grad, True)
+        dx = K.moe_dispatch_bwd(d_in.view(E * C, H), st, dlogits, sp.wg.data, H)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+# ------------------------------------------------------------------------------------------ loss head
+class DistillHead(torch.autograd.Function):
+    """Fused lm_head + distillation / LM / sequence-logp losses on the rows that carry loss only.
+
+    hidden[T,H] -> gather rows -> lm_head GEMM -> ONE-pass row kernel -> per-segment sums.
+    Returns (kd_sum[nseg], kd_cnt[nseg], ce_sum[nseg], ce_cnt[nseg]) so callers form
+      align = -kd_sum/kd_cnt                                  (align_trainer.py:526)
+      lm    =  ce_sum/ce_cnt                                  (llava_qwen2_moe.py:411-421)
+      logp  = -ce_sum per sample                              (dpo_trainer.py:483-495)
+    with scalar torch math.  Never materialises [T, V] logits."""
+
+    @staticmethod
+    def forward(ctx, hidden, head, plan, teacher_logits, *params):
+        H = hidden.shape[1]
+        rows = K.gather_rows(hidden, None, plan.row_idx, H)                    # [R, H]
+        logits = linear_fwd(rows, head)                                         # [R, Vs] bf16
+        Vs = head.w.shape[0]
+        Va = plan.align_vocab if teacher_logits is not None else Vs
+        stats = K.rowloss_fwd(logits, Vs, teacher_logits, Va, plan.ce_label)
+        kd_sum, kd_cnt = K.segment_wsum(stats, 3, plan.kd_w, plan.seg_off)
+        ce_sum, ce_cnt = K.segment_wsum(stats, 4, plan.ce_w, plan.seg_off)
+        ctx.head, ctx.plan, ctx.Va = head, plan, Va
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(logits, stats, teacher_logits, rows if head.requires_grad else None)
+        ctx.mark_non_differentiable(kd_cnt, ce_cnt)
+        return kd_sum, kd_cnt, ce_sum, ce_cnt
+
+    @staticmethod
+    def backward(ctx, g_kd, _g1, g_ce, _g2):
+        logits, stats, t_logits, rows = ctx.saved_tensors
+        plan, head = ctx.plan, ctx.head
+        Vs = head.w.shape[0]
+        nseg = plan.seg_off.numel() - 1
+        zero = torch.zeros(nseg, device=logits.device, dtype=torch.float32)
+        # rowloss_bwd computes ds = ckd*(q - p): that is -ckd * d(x_kd)/ds, hence the sign flip on g_kd
+        kd_scale = (-g_kd).contiguous().float() if g_kd is not None else zero
+        ce_scale = g_ce.contiguous().float() if g_ce is not None else zero
+        K.rowloss_bwd(logits, Vs, t_logits, ctx.Va, plan.ce_label, stats, plan.kd_w, plan.ce_w, plan.seg_id,
+                      kd_scale, ce_scale)                                       # in place over the logits
+        d_rows = linear_dgrad(logits, head)
+        if head.requires_grad:
+            linear_wgrad(logits, rows, head)
+        dh = K.gather_rows(d_rows, None, plan.inv_row_idx, d_rows.shape[1])    # scatter back, zeros elsewhere
+        return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# ------------------------------------------------------------------------------------------ plain linear
+class Linear(torch.autograd.Function):
+    """y = x @ W^T + b as one GEMM launch (used for the full-vocabulary `outputs.logits` path)."""
+
+    @staticmethod
+    def forward(ctx, x, fw, *params):
+        y = linear_fwd(x, fw)
+        ctx.fw = fw
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x if fw.requires_grad else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = linear_dgrad(dy, ctx.fw)
+        if ctx.fw.requires_grad:
+            linear_wgrad(dy, x, ctx.fw)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -1,0 +1,123 @@
+"""AlignTrainer — mimic distillation step (reference train/align_trainer.py:180; compute_loss :530-594,
+get_p :455-477, get_logp :479-501, compute_align_loss :503-528).
+
+The reference materialises teacher probabilities and student log-probabilities as fp32 [B,S',151936]
+tensors and makes >= 6 passes over them.  `compute_loss` here produces the SAME scalars
+(loss, loss/align, loss/moe_balance, loss/lm) from a fused path: lm_head GEMMs only on the rows that
+carry loss, one row kernel for softmax(t) x log_softmax(s) + shifted CE, segment sums; backward
+writes d(logits) in place and runs the dgrad GEMM.  This class is the loss step only — the HF
+Trainer / DeepSpeed control plane around it is out of scope (llavamod.engine drives the step).
+"""
+from collections import defaultdict
+from types import SimpleNamespace
+
+import torch
+
+from .. import kernels as K
+from .. import ops
+from ..constants import ALIGN_VOCAB
+from ..model.language_model.llava_qwen2 import build_loss_plan
+
+
+class AlignTrainer:
+    def __init__(self, model, ref_model, args=None, loss_type="only_kd", moe_loss_enable=True, label_pad_token_id=-100,
+                 align_vocab=ALIGN_VOCAB):
+        self.model, self.ref_model = model, ref_model
+        self.args = args if args is not None else SimpleNamespace(moe_enable=True, distill_all_tokens=False)
+        self.loss_type = getattr(self.args, "loss_type", loss_type)
+        self.moe_loss_enable = getattr(self.args, "moe_loss_enable", moe_loss_enable)
+        self.label_pad_token_id = label_pad_token_id
+        self.align_vocab = align_vocab
+        self._stored_metrics = defaultdict(lambda: defaultdict(list))
+        if ref_model is not None:
+            ref_model.eval()                                   # align_trainer.py:450
+            for p in ref_model.parameters():
+                p.requires_grad_(False)
+
+    # ---- fused step -------------------------------------------------------------------------------
+    def _plan(self, info, device, kd=True, ce=True):
+        Va = min(self.align_vocab, self.model.vocab_size, self.ref_model.vocab_size)
+        return build_loss_plan(info.labels_np, info.lens_np, kd_rows=kd, ce_rows=ce,
+                               distill_all_tokens=getattr(self.args, "distill_all_tokens", False), align_vocab=Va,
+                               device=device)
+
+    def compute_loss(self, model, inputs, return_outputs=False):
+        assert self.ref_model is not None, "ref model can not be none!"
+        batch = dict(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
+                     labels=inputs.get("labels"), images=inputs.get("images"))
+        with torch.no_grad():                                  # teacher forward (:556-560)
+            t_hidden, _, t_info = self.ref_model.forward_hidden(**batch)
+            plan = self._plan(t_info, t_hidden.device)
+            t_rows = K.gather_rows(t_hidden, None, plan.row_idx, t_hidden.shape[1])
+            t_logits = ops.linear_fwd(t_rows, self.ref_model.head())          # [R, Vt] bf16, loss rows only
+            del t_hidden, t_rows
+        s_hidden, moe_list, _ = model.forward_hidden(**batch)                  # student forward (:562)
+        kd_sum, kd_cnt, ce_sum, ce_cnt = ops.DistillHead.apply(s_hidden, model.head(), plan, t_logits,
+                                                               *model._head_trainable())
+        align_loss = -(kd_sum.sum() / kd_cnt.sum())                            # :526
+        policy_sft_loss = ce_sum.sum() / ce_cnt.sum()                          # CrossEntropyLoss(), shifted
+        moe_all = model.moe_loss_from_list(moe_list) if hasattr(model, "moe_loss_from_list") else None
+        if moe_all is not None:
+            policy_sft_loss = policy_sft_loss + moe_all                        # outputs.loss already carries it
+        policy_moe_loss = moe_all if (getattr(self.args, "moe_enable", True) and self.moe_loss_enable) else None
+        losses = align_loss if self.loss_type == "only_kd" else align_loss + policy_sft_loss   # :570-573
+        if policy_moe_loss is not None and bool(policy_moe_loss):              # `if policy_moe_loss:` (:575)
+            moe_loss = policy_moe_loss
+            losses = losses + moe_loss
+        else:
+            moe_loss = torch.full_like(align_loss, -1.0)
+        outputs = {"loss": losses.mean(), "loss/align": align_loss.mean(), "loss/moe_balance": moe_loss.mean(),
+                   "loss/lm": policy_sft_loss.mean()}
+        self.store_metrics({k: v.detach() for k, v in outputs.items()}, train_eval="train")
+        return (losses.mean(), outputs) if return_outputs else losses.mean()
+
+    def training_step(self, model, inputs):
+        loss = self.compute_loss(model, inputs)
+        loss.backward()
+        return loss.detach()
+
+    def store_metrics(self, metrics, train_eval="train"):
+        for k, v in metrics.items():
+            self._stored_metrics[train_eval][k].append(v)
+
+    # ---- materialising API of the reference (slow path, kept for drop-in parity) ------------------
+    def get_p(self, model, inputs):
+        """Teacher probabilities softmax(logits[:, :, :151936], fp32) — materialised like the reference."""
+        outputs = model(**inputs, return_dict=True)
+        logits, labels = outputs.logits, outputs.labels
+        if logits.shape[:-1] != labels.shape:
+            raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape.")
+        moe_loss = outputs.moe_loss if (getattr(self.args, "moe_enable", True) and self.moe_loss_enable
+                                        and "moe_loss" in outputs) else None
+        return _row_softmax(logits, self.align_vocab, log=False), outputs.loss, moe_loss
+
+    def get_logp(self, model, inputs):
+        outputs = model(**inputs, return_dict=True)
+        logits, labels = outputs.logits, outputs.labels
+        if logits.shape[:-1] != labels.shape:
+            raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape.")
+        moe_loss = outputs.moe_loss if (getattr(self.args, "moe_enable", True) and self.moe_loss_enable
+                                        and "moe_loss" in outputs) else None
+        return _row_softmax(logits, self.align_vocab, log=True), outputs.loss, moe_loss, labels
+
+    def compute_align_loss(self, policy_logprobs, reference_probs, labels):
+        """-(sum_v p*logp masked where logp is inf, over label rows) / #label rows (:503-528) on materialised
+        tensors; forward-only helper (the training path is `compute_loss`)."""
+        V = policy_logprobs.shape[-1]
+        lp = policy_logprobs.reshape(-1, V).contiguous()
+        p = reference_probs.reshape(-1, V).contiguous()
+        x = K.rowdot_masked(p, lp)
+        if getattr(self.args, "distill_all_tokens", False):
+            mask = torch.ones_like(labels).reshape(-1).float()
+        else:
+            mask = (labels != self.label_pad_token_id).reshape(-1).float()
+        off = torch.tensor([0, x.numel()], dtype=torch.int32, device=x.device)
+        s, w = K.segment_wsum(x.view(-1, 1), 0, mask.contiguous(), off)
+        return -(s[0] / w[0])
+
+
+def _row_softmax(logits, align_vocab, log):
+    B, S, V = logits.shape
+    Va = min(align_vocab, V)
+    flat = logits.reshape(B * S, V)
+    return K.row_softmax_f32(flat, Va, log).view(B, S, Va)

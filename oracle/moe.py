@@ -29,15 +29,17 @@ def _one_hot_float(idx, n):
     return F.one_hot(idx, num_classes=n).float()
 
 
-def top2gating(logits, capacity_factor, min_capacity, noise=None):
-    """sharded_moe.top2gating.  logits [S,E] fp32; noise [S,E] added to the logits for the 2nd pick."""
+def top2gating(logits, capacity_factor, min_capacity, noise=None, forced=None):
+    """sharded_moe.top2gating.  logits [S,E] fp32; noise [S,E] added to the logits for the 2nd pick.
+    forced=(idx1, idx2): use these expert picks instead of the argmaxes (test hook: lets a parity test
+    separate argmax tie-breaks under bf16 noise from everything else)."""
     S, E = logits.shape
     gates = F.softmax(logits, dim=1)
     C = capacity(S, E, capacity_factor * 2, min_capacity)
-    idx1 = torch.argmax(gates, dim=1)
+    idx1 = torch.argmax(gates, dim=1) if forced is None else forced[0].long()
     mask1 = F.one_hot(idx1, num_classes=E)
     lw = logits if noise is None else logits + noise
-    idx2 = torch.argmax(lw.masked_fill(mask1.bool(), float("-inf")), dim=1)
+    idx2 = torch.argmax(lw.masked_fill(mask1.bool(), float("-inf")), dim=1) if forced is None else forced[1].long()
     mask2 = F.one_hot(idx2, num_classes=E)
     loc1 = torch.cumsum(mask1, dim=0) - 1
     loc2 = torch.cumsum(mask2, dim=0) - 1
@@ -112,6 +114,8 @@ class OracleMoE(nn.Module):
             self.mlp = copy.deepcopy(expert)
             self.coefficient = nn.Linear(hidden_size, 2)
         self.noise = None        # [S,E] gumbel noise for the next top-2 forward (explicit input)
+        self.forced = None       # (idx1, idx2) test hook, see top2gating
+        self.last_picks = None
         self.rts_noise = None    # [S,E] uniform noise for the next top-1 forward
 
     def forward(self, hidden_states, used_token=None):
@@ -121,7 +125,12 @@ class OracleMoE(nn.Module):
         logits = F.linear(x.float(), wg.weight.float())
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 2:
-            l_aux, combine, dispatch, exp_counts = top2gating(logits, cf, self.min_capacity, self.noise)
+            l_aux, combine, dispatch, exp_counts = top2gating(logits, cf, self.min_capacity, self.noise, self.forced)
+            g = F.softmax(logits.detach(), dim=1)
+            i1 = torch.argmax(g, dim=1)
+            lw = logits.detach() if self.noise is None else logits.detach() + self.noise
+            i2 = torch.argmax(lw.masked_fill(F.one_hot(i1, g.shape[1]).bool(), float("-inf")), dim=1)
+            self.last_picks = (i1, i2, g, lw)
         else:
             l_aux, combine, dispatch, exp_counts = top1gating(logits, cf, self.min_capacity, self.rts_noise)
         dispatched = torch.einsum("sec,sm->ecm", dispatch.type_as(x), x)

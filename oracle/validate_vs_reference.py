@@ -110,6 +110,19 @@ def tiny_cfgs():
     return vc, sc, tc
 
 
+def small_gpu_cfgs():
+    """Smallest shapes the MI355X kernels accept (head_dim 64): the GPU-side golden case."""
+    vc = VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=1,
+                      image_size=28, patch_size=14, select_layer=-2)
+    sc = DecoderConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, moe_layers_idx=[0], num_experts=4,
+                       top_k_experts=2, capacity_factor=1.5, eval_capacity_factor=2.0, min_capacity=0,
+                       router_aux_loss_coef=0.01)
+    tc = DecoderConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=2)
+    return vc, sc, tc
+
+
 def tiny_batch(seed=1, B=2, T=8, vocab=512, ragged=False):
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(0, vocab - 12, (B, T), generator=g)
@@ -246,8 +259,8 @@ def check_projector_and_clip(R):
     return tmp
 
 
-def build_pair(seed=0):
-    vc, sc, tc = tiny_cfgs()
+def build_pair(seed=0, cfgs=None):
+    vc, sc, tc = cfgs if cfgs is not None else tiny_cfgs()
     teacher = init_weights(LlavaOracle(tc, vc, moe=False), seed=seed + 100)
     student = sync_experts_from_dense(init_weights(LlavaOracle(sc, vc, moe=True), seed=seed))
     return student, teacher
@@ -404,6 +417,7 @@ def write_golden(dpo_known, ref_teacher):
             check("fixture teacher logits == imported reference", t_out.logits, ro.logits, 2e-5)
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLD, "config1_mimic.safetensors"))
     json.dump(meta, open(os.path.join(GOLD, "config1_mimic.json"), "w"), indent=1)
+    write_gpu_small()
     # MoE restatement golden (self-generated: parity unpinned)
     g = torch.Generator().manual_seed(11)
     logits = torch.randn(40, 4, generator=g)
@@ -413,6 +427,40 @@ def write_golden(dpo_known, ref_teacher):
     save_file({"logits": logits, "noise": nz, "top2.l_aux": l_aux.reshape(1), "top2.combine": comb, "top2.exp_counts": cnt,
                "top1.l_aux": l1.reshape(1), "top1.combine": c1, "top1.exp_counts": n1}, os.path.join(GOLD, "moe_gating.safetensors"))
     print("wrote", sorted(os.listdir(GOLD)))
+
+
+def write_gpu_small():
+    """Golden vectors at head_dim 64 for the -m gpu parity test.  Weights are rounded to bf16 first (the
+    GPU path holds bf16 weights); the oracle then computes in fp32 on those values."""
+    from safetensors.torch import save_file
+    student, teacher = build_pair(seed=7, cfgs=small_gpu_cfgs())
+    for m in (student, teacher):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "gate.wg" not in n:
+                    p.copy_(p.to(torch.bfloat16).float())
+    freeze_like_d2s(student)
+    save_file({k: v.contiguous() for k, v in student.state_dict().items()}, os.path.join(GOLD, "gpusmall_student.safetensors"))
+    save_file({k: v.contiguous() for k, v in teacher.state_dict().items()}, os.path.join(GOLD, "gpusmall_teacher.safetensors"))
+    out, meta = {}, {}
+    for tag, ragged, loss_type in (("plain", False, "only_kd"), ("ragged_kdlm", True, "kd_lm")):
+        b = tiny_batch(seed=5, B=2, T=12, ragged=ragged)
+        b["images"] = b["images"].to(torch.bfloat16).float()
+        student.zero_grad(); student.train(); teacher.eval()
+        student.set_gate_noise([None])
+        loss, logs, s_out, t_out = mimic_step(student, teacher, b, loss_type=loss_type, align_vocab=512)
+        for k, v in b.items():
+            out[f"{tag}.batch.{k}"] = v.to(torch.int64) if v.dtype == torch.bool else v
+        out[f"{tag}.student_logits"] = s_out.logits.detach()
+        out[f"{tag}.teacher_logits"] = t_out.logits.detach()
+        out[f"{tag}.labels"] = s_out.labels
+        for n, p in student.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}.grad.{n}"] = p.grad.detach().clone()
+        meta[tag] = {"loss_type": loss_type, "ragged": ragged, "align_vocab": 512,
+                     **{k: float(v) for k, v in logs.items() if v is not None}}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLD, "gpusmall_mimic.safetensors"))
+    json.dump(meta, open(os.path.join(GOLD, "gpusmall_mimic.json"), "w"), indent=1)
 
 
 def main():

