@@ -19,6 +19,7 @@
 // the MFMA operands swapped (D = B_frag x A_frag = C^T tile), every lane ends up holding 16
 // CONTIGUOUS output columns of one output row -> 16-byte coalesced epilogue stores.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmP {
   const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias;
@@ -192,6 +193,230 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
   }
 }
 
+
+// =============================================================================================
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 per wave), phase-pipelined.
+//
+// LDS: 8 half-tile slots of 16 KiB = 2 (double buffer) x {A(mh0), A(mh1), B(nh0), B(nh1)}; a half-tile is
+// 128 rows x 128 B.  A(mh) holds, for both wave rows, the 64 tile rows of M-half mh; B(nh) holds, for the
+// four wave columns, the 32 (permuted) tile columns of N-half nh.  Each K tile is consumed in 4 phases, one
+// 64x32 output quadrant of every wave per phase (16 MFMAs):
+//     P1 (mh0,nh0): read A(mh0) 8 + B(nh0) 4      prefetch A(mh0) of tile t+1
+//     P2 (mh0,nh1): read B(nh1) 4                 prefetch B(nh0)
+//     P3 (mh1,nh1): read A(mh1) 8                 prefetch B(nh1)
+//     P4 (mh1,nh0): read B(nh0) 4                 prefetch A(mh1)
+// so every half-tile is issued >= 3 phases before its first read and 3 half-tiles (6 LDS-DMA loads per
+// thread) stay in flight across the barriers: waits are counted (s_waitcnt vmcnt(4)), never 0, and are
+// placed one phase BEFORE the read they guard (LDS-DMA data is ordered for other waves' ds_reads only by
+// the issuing wave's vmcnt followed by a barrier the reader has passed).  Barriers are raw s_barrier
+// (no fence => no implicit vmcnt(0)).  The two wave rows run staggered by one barrier so that on every
+// SIMD one wave is in its MFMA cluster (s_setprio 1) while the other issues ds_reads / LDS-DMA.
+// The prefetch is issued for tile t+1 even past the end of K (all lanes out of bounds -> zero fill, no
+// memory traffic), which keeps the vmcnt bookkeeping uniform.
+// =============================================================================================
+#define G256_SLOT 16384
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpb = p.tiles_m * p.tiles_n;
+  const int bz = id / tpb;
+  const int r = id - bz * tpb;
+  const int GROUP_M = 4;
+  const int grp = r / (GROUP_M * p.tiles_n);
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int rr = r - grp * GROUP_M * p.tiles_n;
+  const int tm = first_m + rr % gsz, tn = rr / gsz;
+  int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
+  int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
+  const int row0 = tm * 256, col0 = tn * 256;
+  if (row0 >= Mv) return;
+
+  const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda;
+  const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb;
+  const int rowsA = min(256, Mv - row0), rowsB = min(256, p.N - col0);
+  const int Kv8 = (Kv + 7) & ~7;
+  const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
+  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)(rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
+
+  // ---- staging offsets: this wave fills half-tile rows 16*wave + 8*j + (lane>>3), physical chunk lane&7 ----
+  const int cchunk = (lane & 7) ^ (lane >> 3);
+  uint32_t voA[2][2], voB[2][2];      // [half][j]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int hr = wave * 16 + j * 8 + (lane >> 3);                 // half-tile row 0..127
+      const int ra = (hr >> 6) * 128 + h * 64 + (hr & 63);             // A: tile row
+      voA[h][j] = (ra < rowsA) ? (uint32_t)((ra * p.lda + cchunk * 8) * 2) : GEMM_OOB;
+      const int wcs = hr >> 5, rl = hr & 31, ntl = rl >> 4, ii = rl & 15;
+      const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
+      voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+    }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (Kv + 63) >> 6;
+
+  // kind: 0 A(mh0), 1 A(mh1), 2 B(nh0), 3 B(nh1); tile index t (may be >= nkt: fully out of bounds)
+  auto stage = [&](int kind, int t) {
+    const int k0 = t * 64;
+    char* dst = smem + (t & 1) * (4 * G256_SLOT) + kind * G256_SLOT + wave * 2048;
+    const bool dead = (k0 + cchunk * 8 >= Kv);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
+      if (dead) v = GEMM_OOB;
+      if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+    }
+  };
+
+  const int li = lane & 15;
+  const int rdrow = li * 128;
+  const int ph0 = ((lane >> 4) ^ (lane & 7)) * 16;
+  const int ph1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
+
+  bf16x8 af[4][2], bfr[2][2];
+  auto readA = [&](int t, int mh) {
+    const char* s = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT + wr * 8192 + rdrow;
+#pragma unroll
+    for (int ml = 0; ml < 4; ++ml) {
+      af[ml][0] = *(const bf16x8*)(s + ml * 2048 + ph0);
+      af[ml][1] = *(const bf16x8*)(s + ml * 2048 + ph1);
+    }
+  };
+  auto readB = [&](int t, int nh) {
+    const char* s = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT + wc * 4096 + rdrow;
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) {
+      bfr[nl][0] = *(const bf16x8*)(s + nl * 2048 + ph0);
+      bfr[nl][1] = *(const bf16x8*)(s + nl * 2048 + ph1);
+    }
+  };
+#define G256_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define G256_MFMA(MH, NH)                                                                                   \
+  do {                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+      _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                      \
+        _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                    \
+          acc[(MH) * 4 + ml][(NH) * 2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+              bfr[nl][kk], af[ml][kk], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);                         \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  } while (0)
+
+  // prologue: tile 0 in issue order A(mh0), B(nh0), B(nh1), A(mh1); first reads need the first two
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  G256_BARRIER();
+  if (wr == 1) G256_BARRIER();                 // stagger the second wave row by one barrier
+
+  for (int t = 0; t < nkt; ++t) {
+    // ---- P1: quadrant (mh0, nh0) ----
+    readA(t, 0); readB(t, 0);
+    stage(0, t + 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires B(nh1)_t for P2
+    G256_BARRIER();
+    G256_MFMA(0, 0);
+    G256_BARRIER();
+    // ---- P2: quadrant (mh0, nh1) ----
+    readB(t, 1);
+    stage(2, t + 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(mh1)_t for P3
+    G256_BARRIER();
+    G256_MFMA(0, 1);
+    G256_BARRIER();
+    // ---- P3: quadrant (mh1, nh1) ----
+    readA(t, 1);
+    stage(3, t + 1);
+    G256_BARRIER();
+    G256_MFMA(1, 1);
+    G256_BARRIER();
+    // ---- P4: quadrant (mh1, nh0) ----
+    readB(t, 0);
+    stage(1, t + 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(mh0)_{t+1}, B(nh0)_{t+1} for next P1
+    G256_BARRIER();
+    G256_MFMA(1, 0);
+    G256_BARRIER();
+  }
+  if (wr == 0) G256_BARRIER();                 // re-balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the (out-of-bounds) tail prefetch
+#undef G256_MFMA
+#undef G256_BARRIER
+
+  // ---- epilogue: lane holds, for each mt, row (lane&15) and 16 contiguous columns ----
+  const int g = lane >> 4;
+  const int cb = col0 + wc * 64 + g * 16;
+  float bia[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x) bia[x] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float bv = bf2f(p.bias[min(cb + x, p.N - 1)]);
+      bia[x] = (cb + x < p.N) ? bv : 0.f;
+    }
+  }
+  char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : 2);
+  const bool full = (cb + 16 <= p.N) && p.vec_ok;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int row = row0 + wr * 128 + mt * 16 + li;
+    if (row >= Mv) continue;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
+    if (p.act) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
+    }
+    if (p.out_f32) {
+      float* cp = (float*)Cb + (long long)row * p.ldc + cb;
+      if (full) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          f32x4 o = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+          if (p.accumulate) { f32x4 old = *(f32x4*)(cp + 4 * x); o += old; }
+          *(f32x4*)(cp + 4 * x) = o;
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) if (cb + x < p.N) cp[x] = p.accumulate ? cp[x] + v[x] : v[x];
+      }
+    } else {
+      bf16_t* cp = (bf16_t*)Cb + (long long)row * p.ldc + cb;
+      if (full && !p.accumulate) {
+        u32x4 o0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        u32x4 o1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+        *(u32x4*)(cp) = o0;
+        *(u32x4*)(cp + 8) = o1;
+      } else {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+          if (cb + x < p.N) cp[x] = f2bf(p.accumulate ? bf2f(cp[x]) + v[x] : v[x]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 transpose  out[C, ld_out] = in[R, C]^T  (batched).  Each thread transposes an 8x8 block in
 // registers: 8 x 16-byte loads (row-contiguous), 8 x 16-byte stores; lanes are laid out 8 x 8 so
@@ -257,15 +482,30 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   const int esz = out_f32 ? 4 : 2;
   p.vec_ok = (((uintptr_t)C & 15) == 0) && ((((long long)ldc * esz) & 15) == 0) &&
              (((strideC * esz) & 15) == 0);
-  p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
-  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
-  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  static int force_tile = -1;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_128, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    const char* e = getenv("LMOD_GEMM_TILE");
+    force_tile = e ? atoi(e) : 0;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  // 256-tiles pay when the grid still fills the 256 CUs and the padded tile area is not wasteful
+  bool big = (M >= 512 && N >= 256 && (long long)((M + 255) / 256) * ((N + 255) / 256) * batch >= 192) &&
+             ((long long)((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) <= (long long)M * N * 115 / 100 + 65536);
+  if (force_tile == 128) big = false;
+  if (force_tile == 256) big = true;
+  if (big) {
+    if ((long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL || (long long)255 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL)
+      big = false;
+  }
+  const int T = big ? 256 : 128;
+  p.tiles_m = (M + T - 1) / T; p.tiles_n = (N + T - 1) / T;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  if (big) hipLaunchKernelGGL(gemm_nt_256, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  else hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
   return lmod_launch_status();
 }
 
