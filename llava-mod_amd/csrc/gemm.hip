@@ -41,6 +41,39 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+
+// Grouped launch with per-batch live row counts: map the linear block id onto the LIVE (batch, row-tile,
+// col-tile) space only, so the launch behaves like one dense GEMM over the concatenated live rows (same
+// XCD-contiguous, M-grouped walk, no dead tiles inside any XCD's chunk).  Blocks past the live count exit.
+// Returns false if this block has no work.  batch <= GEMM_MAX_GROUPS.
+#define GEMM_MAX_GROUPS 16
+template <int T, int GROUP_M>
+__device__ __forceinline__ bool grouped_tile(const GemmP& p, int& bz, int& tm, int& tn) {
+  int live[GEMM_MAX_GROUPS];
+  int total = 0;
+#pragma unroll
+  for (int e = 0; e < GEMM_MAX_GROUPS; ++e) {
+    live[e] = 0;
+    if (e < p.batch) { live[e] = (min(p.m_valid[e], p.M) + T - 1) / T; total += live[e]; }
+  }
+  const int nlive = total * p.tiles_n;
+  if ((int)blockIdx.x >= nlive) return false;
+  const int id = xcd_remap(blockIdx.x, nlive);
+  const int grp = id / (GROUP_M * p.tiles_n);
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(total - first_m, GROUP_M);
+  const int rr = id - grp * GROUP_M * p.tiles_n;
+  int vr = first_m + rr % gsz;                      // virtual row tile over the concatenated live rows
+  tn = rr / gsz;
+  bz = 0;
+#pragma unroll
+  for (int e = 0; e < GEMM_MAX_GROUPS; ++e) {
+    if (e < p.batch && bz == e && vr >= live[e]) { vr -= live[e]; bz = e + 1; }
+  }
+  tm = vr;
+  return true;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB + B 16 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -50,14 +83,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
   // ---- tile coordinates (XCD-contiguous, grouped along M for L2 panel reuse) ----
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tpb = p.tiles_m * p.tiles_n;
-  const int bz = id / tpb;
+  int bz = id / tpb;
   const int r = id - bz * tpb;
   const int GROUP_M = 8;
   const int grp = r / (GROUP_M * p.tiles_n);
   const int first_m = grp * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int rr = r - grp * GROUP_M * p.tiles_n;
-  const int tm = first_m + rr % gsz, tn = rr / gsz;
+  int tm = first_m + rr % gsz, tn = rr / gsz;
+  if (p.m_valid) {
+    if (p.batch <= GEMM_MAX_GROUPS) {
+      if (!grouped_tile<128, 8>(p, bz, tm, tn)) return;
+    } else {      // many groups: (group, row tile) fastest, N slowest keeps every XCD chunk equally live
+      const int per_col = p.batch * p.tiles_m;
+      tn = id / per_col;
+      const int rem = id - tn * per_col;
+      bz = rem / p.tiles_m;
+      tm = rem - bz * p.tiles_m;
+    }
+  }
   int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
   int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
   const int row0 = tm * 128, col0 = tn * 128;
@@ -215,6 +259,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 // memory traffic), which keeps the vmcnt bookkeeping uniform.
 // =============================================================================================
 #define G256_SLOT 16384
+#ifndef G256_GROUP_M
+#define G256_GROUP_M 4
+#endif
+#ifndef G256_PRIO
+#define G256_PRIO 1
+#endif
+#ifndef G256_STAGGER
+#define G256_STAGGER 1
+#endif
 
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
@@ -224,14 +277,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
 
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tpb = p.tiles_m * p.tiles_n;
-  const int bz = id / tpb;
+  int bz = id / tpb;
   const int r = id - bz * tpb;
-  const int GROUP_M = 4;
+  const int GROUP_M = G256_GROUP_M;
   const int grp = r / (GROUP_M * p.tiles_n);
   const int first_m = grp * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int rr = r - grp * GROUP_M * p.tiles_n;
-  const int tm = first_m + rr % gsz, tn = rr / gsz;
+  int tm = first_m + rr % gsz, tn = rr / gsz;
+  if (p.m_valid) {   // grouped launch: see gemm_nt_128
+    if (p.batch <= GEMM_MAX_GROUPS) {
+      if (!grouped_tile<256, G256_GROUP_M>(p, bz, tm, tn)) return;
+    } else {
+      const int per_col = p.batch * p.tiles_m;
+      tn = id / per_col;
+      const int rem = id - tn * per_col;
+      bz = rem / p.tiles_m;
+      tm = rem - bz * p.tiles_m;
+    }
+  }
   int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
   int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
   const int row0 = tm * 256, col0 = tn * 256;
@@ -310,13 +374,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
   do {                                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                          \
+    if (G256_PRIO) __builtin_amdgcn_s_setprio(1);                                                           \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
       _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                      \
         _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                    \
           acc[(MH) * 4 + ml][(NH) * 2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
               bfr[nl][kk], af[ml][kk], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);                         \
-    __builtin_amdgcn_s_setprio(0);                                                                          \
+    if (G256_PRIO) __builtin_amdgcn_s_setprio(0);                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
   } while (0)
 
@@ -324,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   G256_BARRIER();
-  if (wr == 1) G256_BARRIER();                 // stagger the second wave row by one barrier
+  if (G256_STAGGER && wr == 1) G256_BARRIER();   // stagger the second wave row by one barrier
 
   for (int t = 0; t < nkt; ++t) {
     // ---- P1: quadrant (mh0, nh0) ----
@@ -355,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
     G256_MFMA(1, 0);
     G256_BARRIER();
   }
-  if (wr == 0) G256_BARRIER();                 // re-balance the stagger
+  if (G256_STAGGER && wr == 0) G256_BARRIER();   // re-balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the (out-of-bounds) tail prefetch
 #undef G256_MFMA
 #undef G256_BARRIER
@@ -492,7 +556,8 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
     attr_set = true;
   }
   // 256-tiles pay when the grid still fills the 256 CUs and the padded tile area is not wasteful
-  bool big = (M >= 512 && N >= 256 && (long long)((M + 255) / 256) * ((N + 255) / 256) * batch >= 192) &&
+  const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+  bool big = (M >= 512 && N >= 256 && (t256 >= 160 || (t256 >= 96 && K >= 8192))) &&
              ((long long)((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) <= (long long)M * N * 115 / 100 + 65536);
   if (force_tile == 128) big = false;
   if (force_tile == 256) big = true;

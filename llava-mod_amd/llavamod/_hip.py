@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "liblmod_hip.so")
+LIB_PATH = os.environ.get("LMOD_HIP_LIB", os.path.join(_HERE, "_lib", "liblmod_hip.so"))   # override: kernel A/B tuning only
 
 _P, _I, _Q, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 
