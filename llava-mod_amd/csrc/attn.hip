@@ -60,30 +60,66 @@ __device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk
 }
 
 // Stage the TRANSPOSE of a [64 x HD] tile: T[rho(d)][token] (pitch TP bytes), through registers.
+// Split in two so the global loads can be issued before a compute phase and the LDS writes after it.
 template <int HD>
-__device__ __forceinline__ void stage_transposed(const bf16_t* base /* row0 of tile, head column 0 */, int ld,
-                                                 int rows_valid, char* tT, int tid) {
-  constexpr int NC = HD / 8, KPT = HD / 32;
-  const int dch = tid % NC, t0 = (tid / NC) * KPT;
+struct TStage {
+  static constexpr int NC = HD / 8, KPT = HD / 32;
   u32x4 vr[KPT];
+  __device__ __forceinline__ void load(const bf16_t* base /* row0 of tile, head column 0 */, int ld, int rows_valid, int tid) {
+    const int dch = tid % NC, t0 = (tid / NC) * KPT;
 #pragma unroll
-  for (int a = 0; a < KPT; ++a) {
-    if (t0 + a < rows_valid) vr[a] = *(const u32x4*)(base + (long long)(t0 + a) * ld + dch * 8);
-    else vr[a] = (u32x4){0u, 0u, 0u, 0u};
-  }
-#pragma unroll
-  for (int dd = 0; dd < 8; ++dd) {
-    const int r = rho_row(dch * 8 + dd);
-    uint32_t e[KPT];
-#pragma unroll
-    for (int a = 0; a < KPT; ++a) { const uint32_t w = vr[a][dd >> 1]; e[a] = (dd & 1) ? (w >> 16) : (w & 0xffffu); }
-    if constexpr (KPT == 4) {
-      u32x2 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
-      *(u32x2*)(tT + r * TP + t0 * 2) = o;
-    } else {
-      *(uint32_t*)(tT + r * TP + t0 * 2) = e[0] | (e[1] << 16);
+    for (int a = 0; a < KPT; ++a) {
+      if (t0 + a < rows_valid) vr[a] = *(const u32x4*)(base + (long long)(t0 + a) * ld + dch * 8);
+      else vr[a] = (u32x4){0u, 0u, 0u, 0u};
     }
   }
+  __device__ __forceinline__ void write(char* tT, int tid) const {
+    const int dch = tid % NC, t0 = (tid / NC) * KPT;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      const int r = rho_row(dch * 8 + dd);
+      uint32_t e[KPT];
+#pragma unroll
+      for (int a = 0; a < KPT; ++a) { const uint32_t w = vr[a][dd >> 1]; e[a] = (dd & 1) ? (w >> 16) : (w & 0xffffu); }
+      if constexpr (KPT == 4) {
+        u32x2 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+        *(u32x2*)(tT + r * TP + t0 * 2) = o;
+      } else {
+        *(uint32_t*)(tT + r * TP + t0 * 2) = e[0] | (e[1] << 16);
+      }
+    }
+  }
+};
+
+// Row-major [64 x HD] tile through registers (same swizzled image as stage_rows / read_rows).  Used
+// where loads must overlap MFMAs: hipcc drains vmcnt(0) before any ds_read while an LDS-DMA is in
+// flight, but tracks plain global loads precisely, so the T14 split (load early, ds_write late) needs them.
+template <int HD>
+struct RStage {
+  static constexpr int NC = HD / 8, NL = 64 * NC / 256;     // 16-byte chunks per thread
+  u32x4 vr[NL];
+  __device__ __forceinline__ void load(const bf16_t* base, int ld, int rows_valid, int tid) {
+#pragma unroll
+    for (int a = 0; a < NL; ++a) {
+      const int id = tid + a * 256, row = id / NC, ch = id % NC;
+      if (row < rows_valid) vr[a] = *(const u32x4*)(base + (long long)row * ld + ch * 8);
+      else vr[a] = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  __device__ __forceinline__ void write(char* tile, int tid) const {
+#pragma unroll
+    for (int a = 0; a < NL; ++a) {
+      const int id = tid + a * 256, row = id / NC, ch = id % NC;
+      *(u32x4*)(tile + row * (HD * 2) + ((ch ^ (row & (NC - 1))) << 4)) = vr[a];
+    }
+  }
+};
+
+template <int HD>
+__device__ __forceinline__ void stage_transposed(const bf16_t* base, int ld, int rows_valid, char* tT, int tid) {
+  TStage<HD> st;
+  st.load(base, ld, rows_valid, tid);
+  st.write(tT, tid);
 }
 
 // Operand from a transposed image for reduction step st (32 tokens): slots j<4 = tokens
@@ -108,8 +144,7 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   constexpr int KS = HD / 32, DT = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;                 // 64 x HD bf16, swizzled
-  char* sVt = smem + 64 * HD * 2;  // HD rows x TP
+  constexpr int KB = 64 * HD * 2, VB = HD * TP;     // K tile bytes, V^T tile bytes; two buffers of each
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy blocks first
@@ -137,20 +172,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
   const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
   const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
   const float c = p.scale * 1.4426950408889634f;
   const int kv_end = CAUSAL ? min(q0 + 128, len) : len;
   const int ntiles = (kv_end + 63) >> 6;
 
+  // prologue: tile 0 into buffer 0
+  TStage<HD> vst;
+  RStage<HD> kst;
+  if (ntiles > 0) {
+    kst.load(Kb, p.ldk, S, tid);
+    vst.load(Vb, p.ldv, S, tid);
+    kst.write(smem, tid);
+    vst.write(smem + 2 * KB, tid);
+  }
+  __syncthreads();
+  // hipcc's waitcnt pass keeps loop-carried "pending load" state for the Q fragments and would drain
+  // vmcnt(0) (killing the prefetch overlap) at their first use in every iteration: make them opaque.
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+
   for (int j = 0; j < ntiles; ++j) {
     const int kv0 = j * 64;
-    __syncthreads();
-    stage_rows<HD>(rsK, sK, wave, lane, kv0, S, p.ldk);
-    stage_transposed<HD>(Vb + (long long)kv0 * p.ldv, p.ldv, S - kv0, sVt, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (CAUSAL && kv0 > qw0 + 31) continue;      // wave-uniform: nothing visible to this wave
+    const char* sK = smem + (j & 1) * KB;
+    const char* sVt = smem + 2 * KB + (j & 1) * VB;
+    const bool more = (j + 1 < ntiles);
+    if (more) {        // prefetch tile j+1 into registers; the loads fly under this tile's MFMAs
+      kst.load(Kb + (long long)(kv0 + 64) * p.ldk, p.ldk, S - kv0 - 64, tid);
+      vst.load(Vb + (long long)(kv0 + 64) * p.ldv, p.ldv, S - kv0 - 64, tid);
+    }
+    if (!(CAUSAL && kv0 > qw0 + 31)) {      // wave-uniform: something visible to this wave
 
     f32x4 s[2][4];
 #pragma unroll
@@ -212,6 +264,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
       }
+    }   // active wave
+    if (more) {
+      kst.write(smem + ((j + 1) & 1) * KB, tid);
+      vst.write(smem + 2 * KB + ((j + 1) & 1) * VB, tid);
+    }
+    __syncthreads();
   }
 
 #pragma unroll
@@ -537,7 +595,7 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
   const dim3 grid((S + 127) / 128, nh, B);
-  const int lds = 64 * hd * 2 + hd * TP;
+  const int lds = 2 * (64 * hd * 2 + hd * TP);
   if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), lds, stream, p); }
   else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), lds, stream, p); }
   else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, stream, p); }

@@ -25,17 +25,17 @@ static inline int lmod_launch_status() {
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rounding torch uses.
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+// fp32 -> bf16, round-to-nearest-even: gfx950 has v_cvt_pk_bf16_f32; clang emits it for __bf16
+// conversions (a hand-rolled integer rounding costs ~8 VALU ops per element and made the attention
+// softmax VALU-issue-bound).
+typedef __bf16 lmod_bf2 __attribute__((ext_vector_type(2)));
+typedef float lmod_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  lmod_f2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, lmod_bf2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bfround(float f) { return __uint_as_float(pack2bf(f, 0.f) << 16); }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
