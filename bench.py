@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--micro-batch", type=int, default=16)
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage", default="mimic", choices=["mimic"])
@@ -219,7 +219,8 @@ def main():
                        "micro_batch_per_gpu": B, "global_batch": B * world, "seq_len": 2048, "response_tokens": 512,
                        "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)",
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
-                       "final_loss": round(loss_val, 4)},
+                       "final_loss": round(loss_val, 4),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "basis": "52.98 algorithmic TFLOP/sample (BASELINE.md) x samples/s / n_gpus",

@@ -61,15 +61,17 @@ __device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk
 
 // Stage the TRANSPOSE of a [64 x HD] tile: T[rho(d)][token] (pitch TP bytes), through registers.
 // Split in two so the global loads can be issued before a compute phase and the LDS writes after it.
+// Per-thread global byte offsets are 32-bit (added to a wave-uniform tile base -> saddr loads).
 template <int HD>
 struct TStage {
   static constexpr int NC = HD / 8, KPT = HD / 32;
   u32x4 vr[KPT];
   __device__ __forceinline__ void load(const bf16_t* base /* row0 of tile, head column 0 */, int ld, int rows_valid, int tid) {
     const int dch = tid % NC, t0 = (tid / NC) * KPT;
+    const uint32_t off0 = (uint32_t)(t0 * ld + dch * 8) * 2u;
 #pragma unroll
     for (int a = 0; a < KPT; ++a) {
-      if (t0 + a < rows_valid) vr[a] = *(const u32x4*)(base + (long long)(t0 + a) * ld + dch * 8);
+      if (t0 + a < rows_valid) vr[a] = *(const u32x4*)((const char*)base + (off0 + (uint32_t)(a * ld) * 2u));
       else vr[a] = (u32x4){0u, 0u, 0u, 0u};
     }
   }
@@ -78,14 +80,15 @@ struct TStage {
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
       const int r = rho_row(dch * 8 + dd);
-      uint32_t e[KPT];
-#pragma unroll
-      for (int a = 0; a < KPT; ++a) { const uint32_t w = vr[a][dd >> 1]; e[a] = (dd & 1) ? (w >> 16) : (w & 0xffffu); }
+      // v_perm_b32: (lo16(a) | lo16(b) << 16) / (hi16(a) | hi16(b) << 16)
+      const uint32_t sel = (dd & 1) ? 0x07060302u : 0x05040100u;
+      const uint32_t p01 = __builtin_amdgcn_perm(vr[1][dd >> 1], vr[0][dd >> 1], sel);
       if constexpr (KPT == 4) {
-        u32x2 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+        const uint32_t p23 = __builtin_amdgcn_perm(vr[3][dd >> 1], vr[2][dd >> 1], sel);
+        u32x2 o = {p01, p23};
         *(u32x2*)(tT + r * TP + t0 * 2) = o;
       } else {
-        *(uint32_t*)(tT + r * TP + t0 * 2) = e[0] | (e[1] << 16);
+        *(uint32_t*)(tT + r * TP + t0 * 2) = p01;
       }
     }
   }
@@ -102,7 +105,7 @@ struct RStage {
 #pragma unroll
     for (int a = 0; a < NL; ++a) {
       const int id = tid + a * 256, row = id / NC, ch = id % NC;
-      if (row < rows_valid) vr[a] = *(const u32x4*)(base + (long long)row * ld + ch * 8);
+      if (row < rows_valid) vr[a] = *(const u32x4*)((const char*)base + (uint32_t)(row * ld + ch * 8) * 2u);
       else vr[a] = (u32x4){0u, 0u, 0u, 0u};
     }
   }
@@ -123,7 +126,9 @@ __device__ __forceinline__ void stage_transposed(const bf16_t* base, int ld, int
 }
 
 // Operand from a transposed image for reduction step st (32 tokens): slots j<4 = tokens
-// 32st + g*4 + j, slots j>=4 = tokens 32st + 16 + g*4 + (j-4).
+// 32st + g*4 + j, slots j>=4 = tokens 32st + 16 + g*4 + (j-4).  (A 128-byte-pitch, XOR-swizzled image
+// with one ds_read_b128 per operand was tried: its transposed ds_write_b64s are 8-way bank-conflicted
+// and the kernel got 7-15 % slower.)
 __device__ __forceinline__ bf16x8 read_transposed(const char* tT, int dtile, int st, int li, int g) {
   const char* p = tT + ((dtile >> 2) * 64 + (dtile & 3) * 16 + li) * TP + (st * 32 + g * 4) * 2;
   const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 32);
@@ -169,6 +174,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[qt][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+  f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(zero4));          // keep ONE zero tile live instead of re-materialising 32 zeros per K/V tile
 
   const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
   const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
@@ -206,53 +213,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
     f32x4 s[2][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) s[qt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const bf16x8 kf = read_rows<HD>(sK, nt * 16 + li, ks * 4 + g);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][nt], 0, 0, 0);
+        for (int qt = 0; qt < 2; ++qt)     // first k-step accumulates onto a loop-invariant zero (no per-tile clears)
+          s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : s[qt][nt], 0, 0, 0);
       }
     const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int q = qw0 + qt * 16 + li;
-      float mx = -INFINITY;
+      float mx = -INFINITY;                       // running max is kept in RAW score units; c > 0
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s[qt][nt][r] * c;
+          float v = s[qt][nt][r];
           if (need_mask) {
             const int key = kv0 + nt * 16 + g * 4 + r;
             if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
+            s[qt][nt][r] = v;
           }
-          s[qt][nt][r] = v;
           mx = fmaxf(mx, v);
         }
       mx = xmax16(mx);
       const float mnew = fmaxf(mrun[qt], mx);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c);
+      const float nmc = -msafe * c;
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[qt][nt][r] - msafe);
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][nt][r], c, nmc));
           s[qt][nt][r] = pv;
           rs += pv;
         }
       rs = xsum16(rs);
       lrun[qt] = lrun[qt] * alpha + rs;
       mrun[qt] = mnew;
+      if (!__all(alpha == 1.f)) {                  // wave-uniform: most tiles do not move any row max
 #pragma unroll
-      for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
+        for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
+      }
       pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
       pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
     }
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     }
     if (g == 0 && p.LSE)
       p.LSE[((long long)b * p.nh + h) * S + q] =
-          (lrun[qt] > 0.f) ? (mrun[qt] + __builtin_amdgcn_logf(lrun[qt])) * 0.6931471805599453f : -INFINITY;
+          (lrun[qt] > 0.f) ? mrun[qt] * p.scale + __builtin_amdgcn_logf(lrun[qt]) * 0.6931471805599453f : -INFINITY;
   }
 }
 
