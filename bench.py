@@ -138,7 +138,9 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=16)
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage", default="mimic", choices=["mimic"])
+    ap.add_argument("--ep", type=int, default=1, help="expert-parallel group size (config 5: --experts 8 --ep 8)")
+    ap.add_argument("--stage", default="mimic", choices=["mimic", "dpo"],
+                    help="mimic = configs 2/3/5 (headline metric); dpo = config 4 (preference distillation, pairs/s)")
     args = ap.parse_args()
 
     from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed, warmup_cosine
@@ -152,7 +154,7 @@ def main():
     B = args.micro_batch
 
     student = LLaVAMoDQwen2ForCausalLM(student_cfg(args.experts), device=dev)
-    student.initialize_moe_modules(moe_model_args(args.experts))
+    student.initialize_moe_modules(moe_model_args(args.experts, ep_size=args.ep))
     for p in student.get_model().mm_projector.parameters():
         p.requires_grad = True                                # initialize_vision_modules (llava_arch.py:115-120)
     teacher = LlavaQwen2ForCausalLM(teacher_cfg(), device=dev)
@@ -161,15 +163,26 @@ def main():
     gb = GradBuffer(student)
     opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0)
     dp = DataParallel()
-    trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
-                                                                    loss_type="kd_lm", moe_loss_enable=True))())
-    batches = [synthetic_batch(B, 1000 * rank + i) for i in range(2)]
+    if args.stage == "mimic":
+        trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                                        loss_type="kd_lm", moe_loss_enable=True))())
+        batches = [synthetic_batch(B, 1000 * rank + i) for i in range(2)]
+    else:       # config 4: chosen / rejected pairs sharing the image; kto_pair is the shell default (preference_distillation.sh:29)
+        from llavamod.train.dpo_trainer import DPOTrainer
+        trainer = DPOTrainer(student, teacher, beta=0.1, loss_type="kto_pair")
+        batches = []
+        for i in range(2):
+            ch, rj = synthetic_batch(B, 1000 * rank + i), synthetic_batch(B, 5000 + 1000 * rank + i)
+            batches.append(dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"],
+                                chosen_attention_mask=ch["attention_mask"], rejected_input_ids=rj["input_ids"],
+                                rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
+                                images=ch["images"]))
     total = args.steps + args.warmup
 
     def step(i):
         gb.zero()
         loss = trainer.training_step(student, batches[i % 2])
-        dp.all_reduce(gb.flat)
+        dp.all_reduce(gb.flat, gb.n_dense, args.ep)
         opt.step(grad_scale=1.0 / world, lr=warmup_cosine(i, max(total, 100), 2e-5))
         return loss
 
@@ -194,7 +207,8 @@ def main():
 
     if rank == 0:
         sps = args.steps * B * world / dt
-        achieved = TFLOP_PER_SAMPLE_LEDGER * sps / world
+        ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
+        achieved = ledger * sps / world
         # dominant kernel, measured live with HIP events on the launch stream (torch's current stream):
         a = torch.randn(B * 2048, 4096, device=dev).to(torch.bfloat16)
         w = torch.randn(22016, 4096, device=dev).to(torch.bfloat16)
@@ -214,8 +228,10 @@ def main():
             "value": round(sps, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, seeded image/token batches)",
-            "config": {"workload": "config 2/3: mimic distillation (kd_lm + moe aux), CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE "
-                                   f"({args.experts} experts, top-2, cf 1.5, 12 MoE layers) student, Qwen1.5-7B teacher",
+            "config": {"workload": ("config 2/3/5: mimic distillation (kd_lm + moe aux)" if args.stage == "mimic" else
+                                    "config 4: preference distillation (kto_pair), value = chosen/rejected PAIRS per second") +
+                                   f", CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({args.experts} experts, top-2, cf 1.5, 12 MoE layers, "
+                                   f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
                        "micro_batch_per_gpu": B, "global_batch": B * world, "seq_len": 2048, "response_tokens": 512,
                        "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)",
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
@@ -223,7 +239,7 @@ def main():
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "basis": "52.98 algorithmic TFLOP/sample (BASELINE.md) x samples/s / n_gpus",
+                         "basis": f"{ledger:.2f} algorithmic TFLOP per unit (BASELINE.md) x units/s / n_gpus",
                          "executed_tflop_per_sample": round(executed_tflop_per_sample(), 2),
                          "dominant_kernel": {"name": "gemm_nt_128 (teacher gate+up shape)", "ms": round(gemm_ms, 4),
                                              "tflops": round(gemm_tf, 1), "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4)}},

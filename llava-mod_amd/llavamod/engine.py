@@ -17,6 +17,39 @@ from .ops import FusedWeight
 BF16 = torch.bfloat16
 
 
+_EP_GROUPS = {}
+
+
+def expert_parallel_group(ep_size):
+    """Ranks [k*ep, (k+1)*ep) form one expert-parallel group (DeepSpeed groups._create_expert_and_data_parallel)."""
+    if ep_size not in _EP_GROUPS:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        assert world % ep_size == 0, "world size must be divisible by ep_size"
+        mine = None
+        for k in range(world // ep_size):
+            g = dist.new_group(list(range(k * ep_size, (k + 1) * ep_size)))
+            if k == rank // ep_size:
+                mine = g
+        _EP_GROUPS[ep_size] = mine
+    return _EP_GROUPS[ep_size]
+
+
+_EDP_GROUPS = {}
+
+
+def expert_data_parallel_group(ep_size):
+    """Ranks holding the SAME experts (rank % ep_size equal): the only ranks an expert gradient is reduced over."""
+    if ep_size not in _EDP_GROUPS:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        mine = None
+        for j in range(ep_size):
+            g = dist.new_group(list(range(j, world, ep_size)))
+            if j == rank % ep_size:
+                mine = g
+        _EDP_GROUPS[ep_size] = mine
+    return _EDP_GROUPS[ep_size]
+
+
 def fused_weights_of(model):
     seen, out = set(), []
     for m in model.modules():
@@ -56,6 +89,10 @@ class GradBuffer:
             if p.requires_grad and id(p) not in covered:
                 spans.append(("p", p, p.numel()))
                 covered.add(id(p))
+        # dense (replicated) parameters first, expert-parallel-sharded expert weights last: two contiguous regions
+        is_exp = lambda sp: bool(getattr(sp[1], "is_expert", False)) and sp[0] == "w"
+        spans = [sp for sp in spans if not is_exp(sp)] + [sp for sp in spans if is_exp(sp)]
+        self.n_dense = sum(n for sp in spans if not is_exp(sp) for n in [sp[2]])
         self.spans = spans
         total = sum(n for _, _, n in spans)
         dev = next(model.parameters()).device
@@ -89,12 +126,19 @@ class DataParallel:
         self.world = dist.get_world_size() if self.enabled else 1
         self.bucket = bucket_bytes // 4
 
-    def all_reduce(self, flat):
+    def all_reduce(self, flat, n_dense=None, ep_size=1):
+        """SUM over the DP world for the first n_dense elements (replicated parameters); the expert region
+        [n_dense:] is reduced only over the ranks that hold the same experts (none when ep_size == world)."""
         if not self.enabled:
             return
+        n_dense = flat.numel() if (n_dense is None or ep_size == 1) else n_dense
         handles = []
-        for lo in range(0, flat.numel(), self.bucket):
-            handles.append(dist.all_reduce(flat[lo:lo + self.bucket], op=dist.ReduceOp.SUM, async_op=True))
+        for lo in range(0, n_dense, self.bucket):
+            handles.append(dist.all_reduce(flat[lo:min(lo + self.bucket, n_dense)], op=dist.ReduceOp.SUM, async_op=True))
+        if n_dense < flat.numel() and self.world // ep_size > 1:
+            g = expert_data_parallel_group(ep_size)
+            for lo in range(n_dense, flat.numel(), self.bucket):
+                handles.append(dist.all_reduce(flat[lo:lo + self.bucket], op=dist.ReduceOp.SUM, group=g, async_op=True))
         for h in handles:
             h.wait()
 

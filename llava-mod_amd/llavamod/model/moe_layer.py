@@ -26,20 +26,20 @@ class _Gate(nn.Module):
 
 
 class _Experts(nn.Module):
-    def __init__(self, expert, n):
+    def __init__(self, expert, n_local, ep_size):
         super().__init__()
-        self.deepspeed_experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(n)])
+        self.deepspeed_experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(n_local)])
         for e in self.deepspeed_experts:
             for p in e.parameters():
                 p.allreduce = False          # deepspeed.moe.experts.Experts tags expert params this way
-                p.group_name = "ep_size_1"
+                p.group_name = f"ep_size_{ep_size}"
 
 
 class _DSMoE(nn.Module):
-    def __init__(self, hidden, expert, num_experts, device):
+    def __init__(self, hidden, expert, num_experts, ep_size, device):
         super().__init__()
         self.gate = _Gate(hidden, num_experts, device)
-        self.experts = _Experts(expert, num_experts)
+        self.experts = _Experts(expert, num_experts // ep_size, ep_size)   # num_local_experts (layer.MoE.__init__)
 
 
 class MoE(nn.Module):
@@ -59,10 +59,14 @@ class MoE(nn.Module):
         self.capacity_factor, self.eval_capacity_factor, self.min_capacity = capacity_factor, eval_capacity_factor, min_capacity
         self.use_rts = use_rts
         device = next(expert.parameters()).device
-        self.deepspeed_moe = _DSMoE(hidden_size, expert, num_experts, device)
+        self.num_local_experts = num_experts // ep_size
+        self.deepspeed_moe = _DSMoE(hidden_size, expert, num_experts, ep_size, device)
         ex = self.deepspeed_moe.experts.deepspeed_experts
         self._gu = FusedWeight([[e.gate_proj.weight, e.up_proj.weight] for e in ex])
         self._down = FusedWeight([[e.down_proj.weight] for e in ex])
+        self._gu.is_expert = self._down.is_expert = True        # engine: not all-reduced across the EP group
+        self.ep_group = None        # torch.distributed group of size ep_size (engine.expert_parallel_group)
+        self.force_decomposed = False   # tests: run the EP code path with ep_size == 1 (identity exchange)
         self.gate_noise = None     # explicit [T, E] Gumbel noise for the next top-2 forward (None: sampled)
         self.deterministic = False  # True: no noise at all (parity tests)
 
@@ -92,6 +96,36 @@ class MoE(nn.Module):
                 noise = -torch.log(-torch.log(u))
         spec = SimpleNamespace(E=self.num_experts, k=self.k, capacity=self.capacity, wg=wg,
                                gu=self._gu.ensure(), down=self._down.ensure())
-        out, l_aux, counts = ops.MoEBlock.apply(x, spec, noise, *self.trainable())
+        if self.ep_size == 1 and not self.force_decomposed:
+            out, l_aux, counts = ops.MoEBlock.apply(x, spec, noise, *self.trainable())
+        else:
+            out, l_aux, counts = self._forward_expert_parallel(x, spec, noise)
         self.last_state = spec.last_state          # routing maps of this call (inspection / tests)
         return out.reshape(shp), l_aux.reshape(()), counts
+
+    def _forward_expert_parallel(self, x, spec, noise):
+        """MOELayer.forward with its two all-to-alls (deepspeed.moe.sharded_moe): route locally over all E
+        experts, exchange [ep, E_local*C, H] capacity slabs, run the local experts on every source rank's
+        slab, exchange back, combine."""
+        import torch.distributed as dist
+        H = x.shape[1]
+        ep, El = self.ep_size, self.num_local_experts
+        if ep > 1 and self.ep_group is None:
+            from ..engine import expert_parallel_group
+            self.ep_group = expert_parallel_group(ep)
+        group = self.ep_group if ep > 1 else None
+        router_params = [wg_p for wg_p in [self.deepspeed_moe.gate.wg.weight] if wg_p.requires_grad]
+        disp, w1, w2, l_aux, counts = ops.MoERoute.apply(x, spec, noise, *router_params)
+        st = spec.last_state
+        C = st.C
+        recv = ops.AllToAll.apply(disp.view(ep, El * C, H), group)
+        rows = st.slots_used.view(ep, El)
+        if group is not None:          # live rows of each incoming slab (tiny int exchange)
+            rr = torch.empty_like(rows)
+            dist.all_to_all_single(rr, rows.contiguous(), group=group)
+            rows = rr
+        expert_params = [q for q in self.deepspeed_moe.experts.parameters() if q.requires_grad]
+        y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rows.contiguous(), *expert_params)
+        back = ops.AllToAll.apply(y.view(ep, El * C, H), group)
+        out = ops.MoECombine.apply(back.reshape(self.num_experts * C, H), w1, w2, st)
+        return out, l_aux, counts

@@ -433,3 +433,167 @@ class Linear(torch.autograd.Function):
         if ctx.fw.requires_grad:
             linear_wgrad(dy, x, ctx.fw)
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ------------------------------------------------------------------------------------------ MoE, expert-parallel form
+# The fused MoEBlock above is the ep_size == 1 fast path.  With experts sharded over an expert-parallel
+# group the layer is the same math cut at the two all-to-all seams of DeepSpeed's MOELayer.forward
+# (einsum dispatch -> all_to_all -> local experts -> all_to_all -> einsum combine):
+#     MoERoute  : x -> (capacity slabs [E*C, H], w1, w2, l_aux, exp_counts)        [local tokens, all E experts]
+#     AllToAll  : [ep, E_local*C, H] slabs exchanged over the EP group (RCCL all_to_all_single; xGMI peers
+#                 each receive their [E_local*C, H] slab directly); backward is the reverse exchange
+#     ExpertFFN : grouped SwiGLU GEMMs of the LOCAL experts over the ep source ranks' slabs
+#     MoECombine: weighted un-permute back to token order
+class MoERoute(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec, noise, *params):
+        T, H = x.shape
+        C = spec.capacity(T)
+        logits = K.moe_router_fwd(x, spec.wg.data)
+        st = K.moe_gate(logits, spec.k, C, noise)
+        disp = K.gather_rows(x, None, st.slot_token, H)
+        ctx.spec, ctx.st, ctx.H = spec, st, H
+        spec.last_state = st
+        ctx.save_for_backward(x)
+        w2 = st.w2 if st.k == 2 else st.w1.new_zeros(1)
+        l_aux, counts = st.l_aux.clone(), st.exp_counts
+        ctx.mark_non_differentiable(counts)
+        return disp, st.w1, w2, l_aux, counts
+
+    @staticmethod
+    def backward(ctx, d_disp, dw1, dw2, dlaux, _dc):
+        sp, st = ctx.spec, ctx.st
+        (x,) = ctx.saved_tensors
+        z = torch.zeros(st.T, device=x.device, dtype=torch.float32)
+        dlogits = K.moe_gate_bwd(st, dw1.contiguous() if dw1 is not None else z,
+                                 (dw2.contiguous() if dw2 is not None else z) if st.k == 2 else None,
+                                 dlaux.contiguous().float() if dlaux is not None else None)
+        if sp.wg.requires_grad:
+            if getattr(sp.wg, "main_grad", None) is None:
+                sp.wg.main_grad = torch.zeros(sp.wg.shape, device=x.device, dtype=torch.float32)
+            K.moe_router_wgrad(x, dlogits, sp.wg.main_grad, True)
+        if d_disp is None:
+            d_disp = torch.zeros((st.E * st.C, ctx.H), device=x.device, dtype=BF16)
+        dx = K.moe_dispatch_bwd(d_disp.contiguous(), st, dlogits, sp.wg.data, ctx.H)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class MoECombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, w1, w2, st):
+        H = y.shape[-1]
+        out = K.moe_combine_fwd(y, st, H)
+        ctx.st, ctx.H = st, H
+        ctx.save_for_backward(y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        dy, dw1, dw2 = K.moe_combine_bwd(dout.contiguous(), y, ctx.st, ctx.H)
+        return dy, dw1, dw2, None
+
+
+class AllToAll(torch.autograd.Function):
+    """Equal-split all_to_all_single over `group` (None: identity, used by the single-GPU test)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        if group is None:
+            return x
+        import torch.distributed as dist
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.group is None:
+            return g, None
+        import torch.distributed as dist
+        out = torch.empty_like(g)
+        dist.all_to_all_single(out, g.contiguous(), group=ctx.group)
+        return out, None
+
+
+class ExpertFFN(torch.autograd.Function):
+    """x: [ep, E_local, C, H] (slabs received from the ep source ranks) -> same shape.  rows: int32
+    [ep, E_local] live rows per slab (from the senders' slots_used) or None (compute every row)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, rows, *params):
+        ep, El, C, H = x.shape
+        I = spec.gu.w.shape[-2] // 2
+        gu = torch.empty((ep, El, C, 2 * I), device=x.device, dtype=BF16)
+        act = torch.empty((ep, El, C, I), device=x.device, dtype=BF16)
+        y = torch.empty_like(x)
+        for le in range(El):          # one grouped launch per local expert: batch = source ranks, shared weights
+            mv = rows[:, le].contiguous() if rows is not None else None
+            wgu = spec.gu.w[le] if spec.gu.stacked else spec.gu.w
+            K.gemm_nt(x[:, le], wgu, out=gu[:, le], M=C, N=2 * I, K=H, lda=H, ldb=H, ldc=2 * I, batch=ep,
+                      strides=(El * C * H, 0, El * C * 2 * I), m_valid=mv)
+        gu2 = gu.view(ep * El * C, 2 * I)
+        rflat = rows.reshape(-1).contiguous() if rows is not None else None
+        K.swiglu_fwd(gu2[:, :I], gu2[:, I:], out=act.view(ep * El * C, I), seg_rows=C, seg_valid=rflat)
+        for le in range(El):
+            mv = rows[:, le].contiguous() if rows is not None else None
+            wd = spec.down.w[le] if spec.down.stacked else spec.down.w
+            K.gemm_nt(act[:, le], wd, out=y[:, le], M=C, N=H, K=I, lda=I, ldb=I, ldc=H, batch=ep,
+                      strides=(El * C * I, 0, El * C * H), m_valid=mv)
+        # rows past a slab's live count are not computed: the receiving combine never reads them (empty slots)
+        ctx.spec, ctx.shape, ctx.I = spec, (ep, El, C, H), I
+        ctx.save_for_backward(x, gu, rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sp = ctx.spec
+        x, gu, rows = ctx.saved_tensors
+        ep, El, C, H = ctx.shape
+        I = ctx.I
+        dy = dy.contiguous()
+        gu_t, down_t = sp.gu.transposed(), sp.down.transposed()
+        dact = torch.empty((ep, El, C, I), device=x.device, dtype=BF16)
+        for le in range(El):
+            mv = rows[:, le].contiguous() if rows is not None else None
+            dt = down_t[le] if sp.down.stacked else down_t
+            K.gemm_nt(dy[:, le], dt, out=dact[:, le], M=C, N=I, K=H, lda=H, ldb=dt.stride(0), ldc=I, batch=ep,
+                      strides=(El * C * H, 0, El * C * I), m_valid=mv)
+        gu2 = gu.view(ep * El * C, 2 * I)
+        rflat = rows.reshape(-1).contiguous() if rows is not None else None
+        if sp.down.requires_grad:
+            act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rflat).view(ep, El, C, I)
+            g = sp.down.grad_buffer()
+            if El == 1:     # slabs of all source ranks are contiguous: ONE wgrad GEMM over K = ep*C (dead rows are zero)
+                K.gemm_nt(K.transpose(dy.view(ep * C, H)), K.transpose(act.view(ep * C, I)),
+                          out=(g[0] if sp.down.stacked else g), out_f32=True, accumulate=True)
+            else:
+                for le in range(El):
+                    for src in range(ep):
+                        kv = rows[src, le:le + 1].contiguous() if rows is not None else None
+                        K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
+                                  out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+            del act
+        dgu = torch.empty_like(gu)
+        dgu2 = dgu.view(ep * El * C, 2 * I)
+        K.swiglu_bwd(dact.view(ep * El * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rflat)
+        dx = torch.empty_like(x)
+        for le in range(El):
+            mv = rows[:, le].contiguous() if rows is not None else None
+            gt = gu_t[le] if sp.gu.stacked else gu_t
+            K.gemm_nt(dgu[:, le], gt, out=dx[:, le], M=C, N=H, K=2 * I, lda=2 * I, ldb=gt.stride(0), ldc=H, batch=ep,
+                      strides=(El * C * 2 * I, 0, El * C * H), m_valid=mv)
+        if sp.gu.requires_grad:
+            g = sp.gu.grad_buffer()
+            if El == 1:
+                K.gemm_nt(K.transpose(dgu.view(ep * C, 2 * I)), K.transpose(x.view(ep * C, H)),
+                          out=(g[0] if sp.gu.stacked else g), out_f32=True, accumulate=True)
+            else:
+                for le in range(El):
+                    for src in range(ep):
+                        kv = rows[src, le:le + 1].contiguous() if rows is not None else None
+                        K.gemm_nt(K.transpose(dgu[src, le]), K.transpose(x[src, le]),
+                                  out=(g[le] if sp.gu.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+        # dx rows past a slab's live count are not computed; the sender's dispatch backward reads live slots only
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

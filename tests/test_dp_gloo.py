@@ -43,17 +43,36 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(gathered, sizes)
     assert all(torch.equal(g, sizes) for g in gathered)
-    # stacked expert weights get ONE contiguous span each (gate/up fused, down), router separately
-    assert gb.numel == 4 * (2 * 128 * 64 + 64 * 128) + 4 * 64
+    # dense (replicated) spans first — here just the router — then ONE contiguous span per stacked expert weight
+    assert gb.numel == 4 * (2 * 128 * 64 + 64 * 128) + 4 * 64 and gb.n_dense == 4 * 64
     ex0 = layer.mlp.deepspeed_moe.experts.deepspeed_experts[0]
-    assert ex0.gate_proj.weight.main_grad.data_ptr() == gb.flat.data_ptr()
+    assert ex0.gate_proj.weight.main_grad.data_ptr() == gb.flat[gb.n_dense:].data_ptr()
     gb.flat.copy_(torch.arange(gb.numel, dtype=torch.float32) * (rank + 1))
     dp = DataParallel(bucket_bytes=4096)                      # force several buckets
     assert dp.enabled and dp.world == world
     dp.all_reduce(gb.flat)
     expect = torch.arange(gb.numel, dtype=torch.float32) * sum(range(1, world + 1))
     assert torch.equal(gb.flat, expect)
-    assert torch.equal(ex0.up_proj.weight.main_grad.reshape(-1), expect[128 * 64:2 * 128 * 64])
+    assert torch.equal(ex0.up_proj.weight.main_grad.reshape(-1), expect[gb.n_dense + 128 * 64:gb.n_dense + 2 * 128 * 64])
+    # expert parallelism over the whole world: router grads are summed, expert grads stay rank-local
+    gb.flat.copy_(torch.arange(gb.numel, dtype=torch.float32) * (rank + 1))
+    dp.all_reduce(gb.flat, n_dense=gb.n_dense, ep_size=world)
+    mine = torch.arange(gb.numel, dtype=torch.float32) * (rank + 1)
+    assert torch.equal(gb.flat[:gb.n_dense], expect[:gb.n_dense]) and torch.equal(gb.flat[gb.n_dense:], mine[gb.n_dense:])
+    # all-to-all of capacity slabs (the EP exchange) and its autograd transpose
+    from llavamod import ops
+    from llavamod.engine import expert_parallel_group
+    grp = expert_parallel_group(world)
+    E_local, C, H = 2, 3, 4
+    send = (torch.arange(world * E_local * C * H, dtype=torch.float32).view(world, E_local * C, H) + 1000 * rank)
+    send.requires_grad_(True)
+    recv = ops.AllToAll.apply(send, grp)
+    for src in range(world):        # chunk `src` of what I hold came from rank src's chunk `rank`
+        exp = torch.arange(world * E_local * C * H, dtype=torch.float32).view(world, E_local * C, H)[rank] + 1000 * src
+        assert torch.equal(recv[src].detach(), exp)
+    (recv * (rank + 1)).sum().backward()                       # grad chunk d returns from rank d scaled by (d+1)
+    for dst in range(world):
+        assert torch.all(send.grad[dst] == dst + 1)
     # rank-distinct synthetic shards (bench.py seeds batches with the rank)
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))

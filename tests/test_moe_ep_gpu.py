@@ -1,0 +1,46 @@
+"""The expert-parallel (decomposed) MoE path — route / all-to-all / local experts / all-to-all / combine —
+must reproduce the fused single-GPU MoE block exactly when the exchange is the identity (ep_size == 1),
+for forward output, aux loss, input gradient and every weight gradient.  (The exchange itself and the
+expert-aware gradient all-reduce are covered on CPU by tests/test_dp_gloo.py.)"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("E,k,T", [(4, 2, 300), (8, 2, 1000), (4, 1, 257)])
+def test_decomposed_equals_fused(E, k, T):
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
+    from llavamod.model.moe_layer import MoE
+    torch.manual_seed(0)
+    cfg = Qwen2Config(hidden_size=256, intermediate_size=512)
+    mlp = init_normal_(Qwen2MLP(cfg, "cuda"), std=0.05, seed=1)
+    a = MoE(256, mlp, num_experts=E, k=k, capacity_factor=1.0, min_capacity=0)
+    with torch.no_grad():
+        for i, e in enumerate(a.deepspeed_moe.experts.deepspeed_experts):     # make experts differ
+            for p in e.parameters():
+                p.mul_(1.0 + 0.1 * i)
+        a.deepspeed_moe.gate.wg.weight.normal_(0, 0.5)
+    b = copy.deepcopy(a)
+    b.force_decomposed = True
+    a.train(); b.train()
+    a.deterministic = b.deterministic = True
+    x = (torch.randn(T, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    dout = torch.randn(T, 256, device="cuda").to(torch.bfloat16)
+    res = []
+    for m in (a, b):
+        xi = x.clone().requires_grad_(True)
+        out, l_aux, counts = m(xi)
+        (out.float() * dout.float()).sum().backward(retain_graph=True)
+        (l_aux * 2.0).backward()
+        grads = {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None}
+        res.append((out.detach(), l_aux.detach(), counts, xi.grad, grads))
+    (o1, l1, c1, g1, w1), (o2, l2, c2, g2, w2) = res
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(c1, c2)
+    assert torch.equal(g1, g2)
+    assert set(w1) == set(w2) and len(w1) == 3 * E + 1
+    for n in w1:
+        d = (w1[n] - w2[n]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, w1[n].abs().max().item()), (n, d)
