@@ -162,7 +162,7 @@ def main():
     n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
     gb = GradBuffer(student)
     opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0)
-    dp = DataParallel()
+    dp = DataParallel().attach(gb, args.ep)
     if args.stage == "mimic":
         trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
                                                                         loss_type="kd_lm", moe_loss_enable=True))())
@@ -182,7 +182,7 @@ def main():
     def step(i):
         gb.zero()
         loss = trainer.training_step(student, batches[i % 2])
-        dp.all_reduce(gb.flat, gb.n_dense, args.ep)
+        dp.finish()                      # spans were all-reduced asynchronously as backward produced them
         opt.step(grad_scale=1.0 / world, lr=warmup_cosine(i, max(total, 100), 2e-5))
         return loss
 

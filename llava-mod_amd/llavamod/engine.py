@@ -113,22 +113,74 @@ class GradBuffer:
 
     def zero(self):
         self.flat.zero_()
+        for kind, obj, _ in self.spans:          # forget uses that never saw a backward (eval-style forwards)
+            if kind == "w":
+                obj.pending = 0
 
 
 class DataParallel:
     """Sample-sharded data parallelism: every rank runs teacher + student on its own micro-batches; the
     only exchange is the SUM all-reduce of the flat gradient buffer at the optimizer boundary (the
     division by world size is folded into AdamW's grad scale).  Loss normalisation stays per-rank, as
-    in the reference (align_trainer.py:526 divides by the local mask sum; DeepSpeed then averages)."""
+    in the reference (align_trainer.py:526 divides by the local mask sum; DeepSpeed then averages).
 
-    def __init__(self, bucket_bytes=512 << 20):
+    Overlap: `attach(gb)` hooks every fused weight; as soon as a weight's last wgrad GEMM of the backward
+    has been enqueued its span is all-reduced asynchronously (RCCL runs on its own stream, ordered after
+    the compute stream by an event), so the exchange hides under the rest of backward.  `finish()` reduces
+    whatever has no hook (router weights, biases) and waits.  Expert weights sharded over an expert-
+    parallel group are reduced only over the ranks that hold the same experts."""
+
+    def __init__(self, bucket_bytes=512 << 20, overlap=True):
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.enabled else 1
         self.bucket = bucket_bytes // 4
+        self.overlap = overlap
+        self.armed = True                 # set False on non-final micro-batches of a gradient-accumulation window
+        self._handles, self._done, self._map = [], set(), {}
+        self.gb, self.ep_size = None, 1
+
+    def attach(self, gb, ep_size=1):
+        self.gb, self.ep_size = gb, ep_size
+        for (kind, obj, n), off in zip(gb.spans, gb.offsets):
+            if kind == "w":
+                self._map[id(obj)] = (off, n, bool(getattr(obj, "is_expert", False)))
+                obj.grad_ready_hook = self._on_ready
+        return self
+
+    def _group_for(self, is_expert):
+        if is_expert and self.ep_size > 1:
+            return expert_data_parallel_group(self.ep_size) if self.world // self.ep_size > 1 else "skip"
+        return None
+
+    def _reduce(self, lo, hi, is_expert):
+        g = self._group_for(is_expert)
+        if g == "skip":
+            return
+        for a in range(lo, hi, self.bucket):
+            self._handles.append(dist.all_reduce(self.gb.flat[a:min(a + self.bucket, hi)], op=dist.ReduceOp.SUM,
+                                                 group=g, async_op=True))
+
+    def _on_ready(self, fw):
+        if not (self.enabled and self.overlap and self.armed) or id(fw) in self._done:
+            return
+        off, n, is_exp = self._map[id(fw)]
+        self._reduce(off, off + n, is_exp)
+        self._done.add(id(fw))
+
+    def finish(self):
+        """Reduce every span that was not already sent by a hook, then wait for all of it."""
+        if self.enabled:
+            for (kind, obj, n), off in zip(self.gb.spans, self.gb.offsets):
+                if id(obj) in self._done:
+                    continue
+                self._reduce(off, off + n, kind == "w" and bool(getattr(obj, "is_expert", False)))
+            for h in self._handles:
+                h.wait()
+        self._handles, self._done = [], set()
 
     def all_reduce(self, flat, n_dense=None, ep_size=1):
-        """SUM over the DP world for the first n_dense elements (replicated parameters); the expert region
-        [n_dense:] is reduced only over the ranks that hold the same experts (none when ep_size == world)."""
+        """Non-overlapped form: SUM over the DP world for the first n_dense elements (replicated parameters);
+        the expert region [n_dense:] is reduced only over the ranks that hold the same experts."""
         if not self.enabled:
             return
         n_dense = flat.numel() if (n_dense is None or ep_size == 1) else n_dense

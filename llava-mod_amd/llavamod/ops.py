@@ -31,6 +31,17 @@ class FusedWeight:
         self._wt_version = None
         self.main_grad = None
         self.bias_main_grad = None
+        self.pending = 0                 # wgrad contributions still to come in the current backward
+        self.grad_ready_hook = None      # engine: called once the last contribution has been enqueued
+
+    def note_use(self):
+        """A forward that will later accumulate into main_grad (called by the fused blocks)."""
+        self.pending += 1
+
+    def grad_done(self):
+        self.pending = max(0, self.pending - 1)
+        if self.pending == 0 and self.grad_ready_hook is not None:
+            self.grad_ready_hook(self)
 
     def __deepcopy__(self, memo):
         # deep copies (MoE up-cycling copies the dense FFN per expert) share nothing and start unfused
@@ -141,6 +152,7 @@ def linear_wgrad(dy, x, fw):
     if fw.bias_requires_grad:
         tmp = K.gemm_nt(dyt, _ones(dyt.shape[1], dy.device), out_f32=True)      # [N, 8]; every column = token sum
         fw.bias_grad_buffer().add_(tmp[:, 0])
+    fw.grad_done()
 
 
 # ------------------------------------------------------------------------------------------ norm
@@ -177,6 +189,10 @@ class AttnBlock(torch.autograd.Function):
         K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         need = any(ctx.needs_input_grad)
+        if need:
+            for fw in (spec.qkv, spec.o):
+                if fw.requires_grad:
+                    fw.note_use()
         o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need)
         out = linear_fwd(o, spec.o)
         ctx.spec = spec
@@ -217,6 +233,9 @@ class MLPBlock(torch.autograd.Function):
         ctx.spec = spec
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, gu)
+            for fw in (spec.gu, spec.down):
+                if fw.requires_grad:
+                    fw.note_use()
         return out
 
     @staticmethod
@@ -262,6 +281,9 @@ class ProjectorBlock(torch.autograd.Function):
         ctx.spec = spec
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(feats, pre)
+            for fw in (spec.fc1, spec.fc2):
+                if fw.requires_grad:
+                    fw.note_use()
         return out
 
     @staticmethod
@@ -327,6 +349,9 @@ class MoEBlock(torch.autograd.Function):
         spec.last_state = st
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, disp, gu, y)
+            for fw in (spec.gu, spec.down):
+                if fw.requires_grad:
+                    fw.note_use()
         l_aux, counts = st.l_aux.clone(), st.exp_counts
         ctx.mark_non_differentiable(counts)
         return out, l_aux, counts
@@ -349,6 +374,7 @@ class MoEBlock(torch.autograd.Function):
             act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rows)
             K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act.view(E, C, I)), out=sp.down.grad_buffer(),
                       out_f32=True, accumulate=True, k_valid=rows)
+            sp.down.grad_done()
             del act
         dgu = torch.empty_like(gu)
         dgu2 = dgu.view(E * C, 2 * I)
@@ -358,6 +384,7 @@ class MoEBlock(torch.autograd.Function):
         if sp.gu.requires_grad:
             K.gemm_nt(K.transpose(dgu), K.transpose(disp.view(E, C, H)), out=sp.gu.grad_buffer(), out_f32=True,
                       accumulate=True, k_valid=rows)
+            sp.gu.grad_done()
         dlogits = K.moe_gate_bwd(st, dw1, dw2, dlaux.contiguous().float() if dlaux is not None else None)
         if sp.wg.requires_grad:
             if getattr(sp.wg, "main_grad", None) is None:
@@ -391,6 +418,8 @@ class DistillHead(torch.autograd.Function):
         ctx.head, ctx.plan, ctx.Va = head, plan, Va
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(logits, stats, teacher_logits, rows if head.requires_grad else None)
+            if head.requires_grad:
+                head.note_use()
         ctx.mark_non_differentiable(kd_cnt, ce_cnt)
         return kd_sum, kd_cnt, ce_sum, ce_cnt
 
@@ -423,6 +452,8 @@ class Linear(torch.autograd.Function):
         ctx.fw = fw
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x if fw.requires_grad else None)
+            if fw.requires_grad:
+                fw.note_use()
         return y
 
     @staticmethod
@@ -544,6 +575,10 @@ class ExpertFFN(torch.autograd.Function):
         # rows past a slab's live count are not computed: the receiving combine never reads them (empty slots)
         ctx.spec, ctx.shape, ctx.I = spec, (ep, El, C, H), I
         ctx.save_for_backward(x, gu, rows)
+        if any(ctx.needs_input_grad):
+            for fw in (spec.gu, spec.down):
+                if fw.requires_grad:
+                    fw.note_use()
         return y
 
     @staticmethod
@@ -574,6 +609,7 @@ class ExpertFFN(torch.autograd.Function):
                         kv = rows[src, le:le + 1].contiguous() if rows is not None else None
                         K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
                                   out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+            sp.down.grad_done()
             del act
         dgu = torch.empty_like(gu)
         dgu2 = dgu.view(ep * El * C, 2 * I)
@@ -595,5 +631,6 @@ class ExpertFFN(torch.autograd.Function):
                         kv = rows[src, le:le + 1].contiguous() if rows is not None else None
                         K.gemm_nt(K.transpose(dgu[src, le]), K.transpose(x[src, le]),
                                   out=(g[le] if sp.gu.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+            sp.gu.grad_done()
         # dx rows past a slab's live count are not computed; the sender's dispatch backward reads live slots only
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

@@ -59,6 +59,17 @@ def _worker(rank, world, port, q):
     dp.all_reduce(gb.flat, n_dense=gb.n_dense, ep_size=world)
     mine = torch.arange(gb.numel, dtype=torch.float32) * (rank + 1)
     assert torch.equal(gb.flat[:gb.n_dense], expect[:gb.n_dense]) and torch.equal(gb.flat[gb.n_dense:], mine[gb.n_dense:])
+    # overlapped form: a weight's hook fires when its last wgrad contribution is in; finish() sweeps the rest
+    gb.flat.copy_(torch.arange(gb.numel, dtype=torch.float32) * (rank + 1))
+    dpo = DataParallel(bucket_bytes=4096).attach(gb)
+    gu = layer.mlp._gu
+    gu.note_use(); gu.note_use()
+    gu.grad_done()
+    assert not dpo._handles                                    # one contribution still pending
+    gu.grad_done()
+    assert dpo._handles and id(gu) in dpo._done
+    dpo.finish()
+    assert torch.equal(gb.flat, expect) and not dpo._handles and not dpo._done
     # all-to-all of capacity slabs (the EP exchange) and its autograd transpose
     from llavamod import ops
     from llavamod.engine import expert_parallel_group
