@@ -12,15 +12,15 @@
 //   accumulators ARE the second operand of the next MFMA (slot j<4 <- key tile 2s, j>=4 <- tile
 //   2s+1): O^T = mfma(first = V^T rows (d), second = P) with V^T read from LDS in the same slot
 //   order.  No LDS round trip, no cross-lane movement for P / dS.
-//   V^T (and K^T, Q^T, dO^T in backward) are built by transposing through registers while
-//   staging; their d-rows are permuted (rho) so each lane ends up with 16 contiguous d values
-//   of one token row -> 16-byte epilogue stores.
+//   V^T (and K^T, Q^T, dO^T in backward) are never materialised: the row-major V/K/Q/dO tiles
+//   already in LDS are read with ds_read_b64_tr_b16 (hardware transpose read, see read_tr), the
+//   per-lane addresses chosen so each lane ends up with 16 contiguous d values of one token row
+//   -> 16-byte epilogue stores.
 // K / V / Q / dO row-major tiles go global->LDS by LDS-DMA with the XOR swizzle applied on the
 // source address (LDS-DMA writes lane-linear) and on the ds_read side.
 #include "common.h"
 
 #define ATT_OOB 0x80000000u
-#define TP 136   // byte pitch of a transposed-tile row (64 tokens * 2 B + 8 B pad): conflict-free b64 reads
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
@@ -30,11 +30,6 @@ struct AttnP {
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   float scale;
 };
-
-__device__ __forceinline__ int rho_row(int d) {   // d (0..HD-1) -> row of the transposed LDS image
-  const int dl = d & 63;
-  return (d & ~63) + (((dl >> 2) & 3) << 4) + ((dl >> 4) << 2) + (dl & 3);
-}
 
 // Stage a [64 x HD] row-major bf16 tile into LDS by LDS-DMA (swizzled).  rs covers the whole
 // [S x ld] matrix of this (batch, head); rows >= S read as zeros.
@@ -59,40 +54,27 @@ __device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk
   return *(const bf16x8*)(tile + row * (HD * 2) + ((chunk ^ (row & (NC - 1))) << 4));
 }
 
-// Stage the TRANSPOSE of a [64 x HD] tile: T[rho(d)][token] (pitch TP bytes), through registers.
-// Split in two so the global loads can be issued before a compute phase and the LDS writes after it.
-// Per-thread global byte offsets are 32-bit (added to a wave-uniform tile base -> saddr loads).
+// "Transposed" MFMA operand straight from a ROW-MAJOR (stage_rows / RStage) tile: rows of the tile are
+// tokens, the operand wants index = feature d (lane&15) and reduction slots = tokens.  gfx950's
+// ds_read_b64_tr_b16 does the transpose at read time: within each 16-lane group, lanes 4r..4r+3 each fetch
+// 4 contiguous bf16 of "row r" from THEIR OWN address and lane i receives column i (one element per row)
+// [semantics probed on hardware: tools/probe/tr_probe.hip].  Rows r = 0..3 are pointed at tokens
+// 32st + 4g + r (second read: +16), i.e. exactly the slot order in which the S^T / dS accumulators hold
+// their tokens; the 4 lanes of a row are pointed at features c4*16 + dt*4 + (0..3) of a 64-wide strip so
+// lane i ends up with feature (i>>2)*16 + dt*4 + (i&3) — the permuted order that leaves every lane 16
+// contiguous output features (16-byte epilogue stores).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <int HD>
-struct TStage {
-  static constexpr int NC = HD / 8, KPT = HD / 32;
-  u32x4 vr[KPT];
-  __device__ __forceinline__ void load(const bf16_t* base /* row0 of tile, head column 0 */, int ld, int rows_valid, int tid) {
-    const int dch = tid % NC, t0 = (tid / NC) * KPT;
-    const uint32_t off0 = (uint32_t)(t0 * ld + dch * 8) * 2u;
-#pragma unroll
-    for (int a = 0; a < KPT; ++a) {
-      if (t0 + a < rows_valid) vr[a] = *(const u32x4*)((const char*)base + (off0 + (uint32_t)(a * ld) * 2u));
-      else vr[a] = (u32x4){0u, 0u, 0u, 0u};
-    }
-  }
-  __device__ __forceinline__ void write(char* tT, int tid) const {
-    const int dch = tid % NC, t0 = (tid / NC) * KPT;
-#pragma unroll
-    for (int dd = 0; dd < 8; ++dd) {
-      const int r = rho_row(dch * 8 + dd);
-      // v_perm_b32: (lo16(a) | lo16(b) << 16) / (hi16(a) | hi16(b) << 16)
-      const uint32_t sel = (dd & 1) ? 0x07060302u : 0x05040100u;
-      const uint32_t p01 = __builtin_amdgcn_perm(vr[1][dd >> 1], vr[0][dd >> 1], sel);
-      if constexpr (KPT == 4) {
-        const uint32_t p23 = __builtin_amdgcn_perm(vr[3][dd >> 1], vr[2][dd >> 1], sel);
-        u32x2 o = {p01, p23};
-        *(u32x2*)(tT + r * TP + t0 * 2) = o;
-      } else {
-        *(uint32_t*)(tT + r * TP + t0 * 2) = p01;
-      }
-    }
-  }
-};
+__device__ __forceinline__ bf16x8 read_tr(const char* tile, int dtile, int st, int lane) {
+  constexpr int NC = HD / 8;
+  const int i = lane & 15, g = lane >> 4;
+  const int tok = st * 32 + g * 4 + (i >> 2);
+  const int chunk = (dtile >> 2) * 8 + (i & 3) * 2 + ((dtile & 3) >> 1);
+  const char* p = tile + tok * (HD * 2) + ((chunk ^ (tok & (NC - 1))) << 4) + (dtile & 1) * 8;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * HD * 2));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
 
 // Row-major [64 x HD] tile through registers (same swizzled image as stage_rows / read_rows).  Used
 // where loads must overlap MFMAs: hipcc drains vmcnt(0) before any ds_read while an LDS-DMA is in
@@ -118,24 +100,6 @@ struct RStage {
   }
 };
 
-template <int HD>
-__device__ __forceinline__ void stage_transposed(const bf16_t* base, int ld, int rows_valid, char* tT, int tid) {
-  TStage<HD> st;
-  st.load(base, ld, rows_valid, tid);
-  st.write(tT, tid);
-}
-
-// Operand from a transposed image for reduction step st (32 tokens): slots j<4 = tokens
-// 32st + g*4 + j, slots j>=4 = tokens 32st + 16 + g*4 + (j-4).  (A 128-byte-pitch, XOR-swizzled image
-// with one ds_read_b128 per operand was tried: its transposed ds_write_b64s are 8-way bank-conflicted
-// and the kernel got 7-15 % slower.)
-__device__ __forceinline__ bf16x8 read_transposed(const char* tT, int dtile, int st, int li, int g) {
-  const char* p = tT + ((dtile >> 2) * 64 + (dtile & 3) * 16 + li) * TP + (st * 32 + g * 4) * 2;
-  const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 32);
-  u32x4 r = {a[0], a[1], b[0], b[1]};
-  return __builtin_bit_cast(bf16x8, r);
-}
-
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
   u32x4 r = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
   return __builtin_bit_cast(bf16x8, r);
@@ -149,7 +113,7 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   constexpr int KS = HD / 32, DT = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KB = 64 * HD * 2, VB = HD * TP;     // K tile bytes, V^T tile bytes; two buffers of each
+  constexpr int KB = 64 * HD * 2, VB = 64 * HD * 2;   // K tile, V tile (both row-major, swizzled); two buffers of each
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy blocks first
@@ -184,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const int ntiles = (kv_end + 63) >> 6;
 
   // prologue: tile 0 into buffer 0
-  TStage<HD> vst;
+  RStage<HD> vst;
   RStage<HD> kst;
   if (ntiles > 0) {
     kst.load(Kb, p.ldk, S, tid);
@@ -203,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   for (int j = 0; j < ntiles; ++j) {
     const int kv0 = j * 64;
     const char* sK = smem + (j & 1) * KB;
-    const char* sVt = smem + 2 * KB + (j & 1) * VB;
+    const char* sV = smem + 2 * KB + (j & 1) * VB;
     const bool more = (j + 1 < ntiles);
     if (more) {        // prefetch tile j+1 into registers; the loads fly under this tile's MFMAs
       kst.load(Kb + (long long)(kv0 + 64) * p.ldk, p.ldk, S - kv0 - 64, tid);
@@ -267,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16x8 vf = read_transposed(sVt, d, st, li, g);
+        const bf16x8 vf = read_tr<HD>(sV, d, st, lane);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
       }
@@ -334,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + 64 * HD * 2;
-  char* sKt = smem + 2 * 64 * HD * 2;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
@@ -379,7 +342,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     __syncthreads();
     stage_rows<HD>(rsK, sK, wave, lane, kv0, S, p.ldk);
     stage_rows<HD>(rsV, sV, wave, lane, kv0, S, p.ldv);
-    stage_transposed<HD>(Kb + (long long)kv0 * p.ldk, p.ldk, S - kv0, sKt, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (CAUSAL && kv0 > qw0 + 31) continue;
@@ -420,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16x8 ktf = read_transposed(sKt, d, st, li, g);
+        const bf16x8 ktf = read_tr<HD>(sK, d, st, lane);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][st], dq[qt][d], 0, 0, 0);
       }
@@ -455,9 +417,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;
   char* sdO = smem + 64 * HD * 2;
-  char* sQt = smem + 2 * 64 * HD * 2;
-  char* sdOt = sQt + HD * TP;
-  float* sLse = (float*)(sdOt + HD * TP);
+  float* sLse = (float*)(smem + 2 * 64 * HD * 2);
   float* sDl = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,8 +461,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
       __syncthreads();
       stage_rows<HD>(rsQ, sQ, wave, lane, q0, S, p.ldq);
       stage_rows<HD>(rsO, sdO, wave, lane, q0, S, p.lddo);
-      stage_transposed<HD>(Qb + (long long)q0 * p.ldq, p.ldq, S - q0, sQt, tid);
-      stage_transposed<HD>(dOb + (long long)q0 * p.lddo, p.lddo, S - q0, sdOt, tid);
       if (tid < 64) sLse[tid] = (q0 + tid < S) ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
       else if (tid < 128) sDl[tid - 64] = (q0 + tid - 64 < S) ? dlb[q0 + tid - 64] : 0.f;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -539,10 +497,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
       const bf16x8 ds0 = pack_frag(dp[0], dp[1]), ds1 = pack_frag(dp[2], dp[3]);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16x8 o0 = read_transposed(sdOt, d, 0, li, g), o1 = read_transposed(sdOt, d, 1, li, g);
+        const bf16x8 o0 = read_tr<HD>(sdO, d, 0, lane), o1 = read_tr<HD>(sdO, d, 1, lane);
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[d], 0, 0, 0);
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[d], 0, 0, 0);
-        const bf16x8 t0 = read_transposed(sQt, d, 0, li, g), t1 = read_transposed(sQt, d, 1, li, g);
+        const bf16x8 t0 = read_tr<HD>(sQ, d, 0, lane), t1 = read_tr<HD>(sQ, d, 1, lane);
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, ds0, dk[d], 0, 0, 0);
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, ds1, dk[d], 0, 0, 0);
       }
@@ -602,7 +560,7 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
   const dim3 grid((S + 127) / 128, nh, B);
-  const int lds = 2 * (64 * hd * 2 + hd * TP);
+  const int lds = 4 * 64 * hd * 2;
   if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), lds, stream, p); }
   else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), lds, stream, p); }
   else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, stream, p); }
@@ -631,8 +589,8 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo);
   const dim3 gq((S + 127) / 128, nh, B), gk((S + 63) / 64, nkv, B);
-  const int lds_q = 2 * 64 * hd * 2 + hd * TP;
-  const int lds_k = 2 * 64 * hd * 2 + 2 * hd * TP + 512;
+  const int lds_q = 2 * 64 * hd * 2;
+  const int lds_k = 2 * 64 * hd * 2 + 512;
 #define LAUNCH_BWD(HDV, CZ)                                                                                        \
   do {                                                                                                             \
     set_lds(attn_bwd_dq_kernel<HDV, CZ>, lds_q);                                                                   \

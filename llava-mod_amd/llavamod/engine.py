@@ -241,7 +241,7 @@ def warmup_cosine(step, total_steps, base_lr, warmup_ratio=0.03):
 
 def init_distributed():
     """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the launcher.  backend "nccl" is RCCL."""
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if "RANK" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not os.environ.get("LMOD_FORCE_DIST")):
         if torch.cuda.is_available():
             torch.cuda.set_device(0)
         return 0, 0, 1
