@@ -4,23 +4,31 @@
 // (call site multimodal_encoder/clip_encoder.py:54).  Causal + right-padding key mask
 // (keys >= seqlens[b] are masked, like the 4-D mask of :1019-1027); GQA via `group`.
 //
+// Geometry: one workgroup = NWAVE waves.  Forward / dQ: 32 queries per wave against K/V tiles of 64 keys;
+// dK/dV: 16 keys per wave against Q/dO tiles of 64 queries.  With 8 waves (256 queries or 128 keys per
+// workgroup) the bytes staged into LDS per flop are half those of a 4-wave workgroup, which ran at the
+// per-CU L2->LDS bandwidth bound.
+//
 // Lane algebra (MFMA 16x16x32; first/second operand share one register layout:
 // index = lane&15, reduction slots = (lane>>4)*8 + j; D[row=(lane>>4)*4+r][col=lane&15]):
 //   S^T tile = mfma(first = K rows, second = Q rows)  -> lane holds 4 keys x ONE query (lane&15)
 //   => row max / row sum are in-lane + two xor-shuffles; alpha, m, l are lane-local.
 //   The reduction-slot order of an MFMA is free as long as both operands agree, so the S^T
 //   accumulators ARE the second operand of the next MFMA (slot j<4 <- key tile 2s, j>=4 <- tile
-//   2s+1): O^T = mfma(first = V^T rows (d), second = P) with V^T read from LDS in the same slot
-//   order.  No LDS round trip, no cross-lane movement for P / dS.
+//   2s+1): O^T = mfma(first = V^T rows (d), second = P).  No LDS round trip, no cross-lane movement.
 //   V^T (and K^T, Q^T, dO^T in backward) are never materialised: the row-major V/K/Q/dO tiles
 //   already in LDS are read with ds_read_b64_tr_b16 (hardware transpose read, see read_tr), the
 //   per-lane addresses chosen so each lane ends up with 16 contiguous d values of one token row
 //   -> 16-byte epilogue stores.
-// K / V / Q / dO row-major tiles go global->LDS by LDS-DMA with the XOR swizzle applied on the
-// source address (LDS-DMA writes lane-linear) and on the ds_read side.
+// Staging: tiles go global -> registers -> LDS (loads issued before a tile's MFMAs, ds_writes after them,
+// double-buffered LDS, one barrier per tile).  LDS-DMA is not used here: hipcc drains vmcnt(0) before any
+// ds_read while an LDS-DMA is in flight, which serialises load and compute.
 #include "common.h"
 
-#define ATT_OOB 0x80000000u
+#ifndef NWAVE
+#define NWAVE 8
+#endif
+#define NTHR (NWAVE * 64)
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
@@ -31,62 +39,70 @@ struct AttnP {
   float scale;
 };
 
-// Stage a [64 x HD] row-major bf16 tile into LDS by LDS-DMA (swizzled).  rs covers the whole
-// [S x ld] matrix of this (batch, head); rows >= S read as zeros.
-template <int HD>
-__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int wave, int lane, int row0,
-                                           int S, int ld) {
-  constexpr int NC = HD / 8, RPW = 1024 / (HD * 2), LPW = 64 / RPW / 4;
-#pragma unroll
-  for (int j = 0; j < LPW; ++j) {
-    const int wl = wave * LPW + j;
-    const int row = wl * RPW + lane / NC;
-    const int ch = (lane % NC) ^ (row & (NC - 1));
-    const uint32_t vo = (row0 + row < S) ? (uint32_t)(row * ld * 2 + ch * 16) : ATT_OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + wl * 1024), 16, vo, row0 * ld * 2, 0, 0);
-  }
-}
-
-// Read one MFMA operand (8 bf16 of row `row`, logical chunk `chunk`) from a stage_rows image.
-template <int HD>
-__device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk) {
-  constexpr int NC = HD / 8;
-  return *(const bf16x8*)(tile + row * (HD * 2) + ((chunk ^ (row & (NC - 1))) << 4));
-}
-
-// "Transposed" MFMA operand straight from a ROW-MAJOR (stage_rows / RStage) tile: rows of the tile are
-// tokens, the operand wants index = feature d (lane&15) and reduction slots = tokens.  gfx950's
-// ds_read_b64_tr_b16 does the transpose at read time: within each 16-lane group, lanes 4r..4r+3 each fetch
-// 4 contiguous bf16 of "row r" from THEIR OWN address and lane i receives column i (one element per row)
-// [semantics probed on hardware: tools/probe/tr_probe.hip].  Rows r = 0..3 are pointed at tokens
-// 32st + 4g + r (second read: +16), i.e. exactly the slot order in which the S^T / dS accumulators hold
-// their tokens; the 4 lanes of a row are pointed at features c4*16 + dt*4 + (0..3) of a 64-wide strip so
-// lane i ends up with feature (i>>2)*16 + dt*4 + (i&3) — the permuted order that leaves every lane 16
-// contiguous output features (16-byte epilogue stores).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-template <int HD>
+
+// ---- LDS tile image: [rows = tokens][HD bf16], 16-byte chunks XOR-swizzled per row.  Swizzles for HD 128:
+//  SW 0  key = row & 15                      conflict-free for ds_read_b128 operand reads (rows = lane&15);
+//                                            4-way conflicts under tr reads
+//  SW 1  key = bit-permutation of row & 15   conflict-free for b128, 2-way for tr (tiles read both ways)
+//  SW 2  key = (row&1) | ((row>>1)&1)<<3, the two 8-byte halves of a chunk swapped when (row>>2)&1:
+//                                            conflict-free for tr reads (tiles read ONLY through read_tr)
+// (tr pattern per half-wave: 8 consecutive tokens x 4 lanes reading 8 bytes of chunks {b, b+2, b+4, b+6}.)
+// HD 64 tiles (ViT) always use key = row & 7.
+template <int HD, int SW>
+__device__ __forceinline__ int swz_key(int row) {
+  if constexpr (HD == 128 && SW == 1)
+    return (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 3) & 1) << 2) | (((row >> 1) & 1) << 3);
+  else if constexpr (HD == 128 && SW == 2)
+    return (row & 1) | (((row >> 1) & 1) << 3);
+  else
+    return row & (HD / 8 - 1);
+}
+template <int HD, int SW>
+__device__ __forceinline__ int swz_half(int row) {
+  if constexpr (HD == 128 && SW == 2) return (row >> 2) & 1;
+  else return 0;
+}
+
+// One MFMA operand (8 bf16 of row `row`, logical chunk `chunk`): ds_read_b128.
+template <int HD, int SW>
+__device__ __forceinline__ bf16x8 read_rows(const char* tile, int row, int chunk) {
+  static_assert(!(HD == 128 && SW == 2), "SW 2 tiles are tr-read only");
+  return *(const bf16x8*)(tile + row * (HD * 2) + ((chunk ^ swz_key<HD, SW>(row)) << 4));
+}
+
+// "Transposed" MFMA operand straight from the row-major tile: the operand wants index = feature d
+// (lane&15) and reduction slots = tokens.  ds_read_b64_tr_b16 transposes at read time: within each 16-lane
+// group, lanes 4r..4r+3 each fetch 4 contiguous bf16 of "row r" from THEIR OWN address and lane i receives
+// column i (one element per row) [semantics probed on hardware: tools/probe/tr_probe.hip].  Rows r = 0..3
+// are pointed at tokens 32st + 4g + r (second read: +16), exactly the slot order in which the S^T / dS
+// accumulators hold their tokens; the 4 lanes of a row are pointed at features c4*16 + dt*4 + (0..3) of a
+// 64-wide strip, so lane i ends up with feature (i>>2)*16 + dt*4 + (i&3): every lane finishes with 16
+// contiguous output features.
+template <int HD, int SW>
 __device__ __forceinline__ bf16x8 read_tr(const char* tile, int dtile, int st, int lane) {
-  constexpr int NC = HD / 8;
   const int i = lane & 15, g = lane >> 4;
   const int tok = st * 32 + g * 4 + (i >> 2);
   const int chunk = (dtile >> 2) * 8 + (i & 3) * 2 + ((dtile & 3) >> 1);
-  const char* p = tile + tok * (HD * 2) + ((chunk ^ (tok & (NC - 1))) << 4) + (dtile & 1) * 8;
+  const char* p = tile + tok * (HD * 2) + ((chunk ^ swz_key<HD, SW>(tok)) << 4) +
+                  (((dtile & 1) ^ swz_half<HD, SW>(tok)) << 3);
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  // token + 16 has the same swizzle key / half as token (they only look at row bits 0..3)
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * HD * 2));
   return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-// Row-major [64 x HD] tile through registers (same swizzled image as stage_rows / read_rows).  Used
-// where loads must overlap MFMAs: hipcc drains vmcnt(0) before any ds_read while an LDS-DMA is in
-// flight, but tracks plain global loads precisely, so the T14 split (load early, ds_write late) needs them.
-template <int HD>
+// [ROWS x HD] row-major tile through registers, split so the global loads can be issued before a compute
+// phase and the LDS writes after it.  Offsets are 32-bit against a wave-uniform base.
+template <int HD, int SW, int ROWS = 64>
 struct RStage {
-  static constexpr int NC = HD / 8, NL = 64 * NC / 256;     // 16-byte chunks per thread
+  static constexpr int NC = HD / 8, NL = ROWS * NC / NTHR;     // 16-byte chunks per thread
+  static_assert(NL >= 1 && NL * NTHR == ROWS * NC, "tile does not divide over the workgroup");
   u32x4 vr[NL];
   __device__ __forceinline__ void load(const bf16_t* base, int ld, int rows_valid, int tid) {
 #pragma unroll
     for (int a = 0; a < NL; ++a) {
-      const int id = tid + a * 256, row = id / NC, ch = id % NC;
+      const int id = tid + a * NTHR, row = id / NC, ch = id % NC;
       if (row < rows_valid) vr[a] = *(const u32x4*)((const char*)base + (uint32_t)(row * ld + ch * 8) * 2u);
       else vr[a] = (u32x4){0u, 0u, 0u, 0u};
     }
@@ -94,8 +110,10 @@ struct RStage {
   __device__ __forceinline__ void write(char* tile, int tid) const {
 #pragma unroll
     for (int a = 0; a < NL; ++a) {
-      const int id = tid + a * 256, row = id / NC, ch = id % NC;
-      *(u32x4*)(tile + row * (HD * 2) + ((ch ^ (row & (NC - 1))) << 4)) = vr[a];
+      const int id = tid + a * NTHR, row = id / NC, ch = id % NC;
+      u32x4 v = vr[a];
+      if (swz_half<HD, SW>(row)) v = (u32x4){v[2], v[3], v[0], v[1]};
+      *(u32x4*)(tile + row * (HD * 2) + ((ch ^ swz_key<HD, SW>(row)) << 4)) = v;
     }
   }
 };
@@ -108,19 +126,37 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 __device__ __forceinline__ float xmax16(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float xsum16(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// Epilogue: lane (index li, group g) owns, per 64-wide strip, the 16 contiguous features g*16 + dt*4 + r.
+template <int HD>
+__device__ __forceinline__ void store_rows16(bf16_t* dst, const f32x4 (&acc)[HD / 16], float mul) {
+#pragma unroll
+  for (int sp = 0; sp < HD / 64; ++sp) {
+    u32x4 w0, w1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      w0[k * 2] = pack2bf(acc[sp * 4 + k][0] * mul, acc[sp * 4 + k][1] * mul);
+      w0[k * 2 + 1] = pack2bf(acc[sp * 4 + k][2] * mul, acc[sp * 4 + k][3] * mul);
+      w1[k * 2] = pack2bf(acc[sp * 4 + 2 + k][0] * mul, acc[sp * 4 + 2 + k][1] * mul);
+      w1[k * 2 + 1] = pack2bf(acc[sp * 4 + 2 + k][2] * mul, acc[sp * 4 + 2 + k][3] * mul);
+    }
+    *(u32x4*)(dst + sp * 64) = w0;
+    *(u32x4*)(dst + sp * 64 + 8) = w1;
+  }
+}
+
 // ============================================================================ forward
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
-  constexpr int KS = HD / 32, DT = HD / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KB = 64 * HD * 2, VB = 64 * HD * 2;   // K tile, V tile (both row-major, swizzled); two buffers of each
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int qb, int h, int b) {
+  constexpr int KS = HD / 32, DT = HD / 16, QB = NWAVE * 32;
+  constexpr int TB = 64 * HD * 2;                       // tile bytes; layout: K[2], V[2]
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));     // per-lane addresses are re-derived per pass, not hoisted (and spilled) across passes
+  const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy blocks first
-  const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
+  const int hk = h / p.group;
   const int S = p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
-  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const int q0 = qb * QB, qw0 = q0 + wave * 32;
   const long long tok0 = (long long)b * S;
 
   bf16x8 qf[2][KS];
@@ -139,22 +175,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     for (int d = 0; d < DT; ++d) o[qt][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
   f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  asm volatile("" : "+v"(zero4));          // keep ONE zero tile live instead of re-materialising 32 zeros per K/V tile
+  asm volatile("" : "+v"(zero4));          // keep ONE zero tile live instead of re-materialising zeros per K/V tile
 
   const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
   const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
   const float c = p.scale * 1.4426950408889634f;
-  const int kv_end = CAUSAL ? min(q0 + 128, len) : len;
+  const int kv_end = CAUSAL ? min(q0 + QB, len) : len;
   const int ntiles = (kv_end + 63) >> 6;
 
-  // prologue: tile 0 into buffer 0
-  RStage<HD> vst;
-  RStage<HD> kst;
+  RStage<HD, 0> kst;        // K: b128 reads only
+  RStage<HD, 2> vst;        // V: tr reads only
   if (ntiles > 0) {
     kst.load(Kb, p.ldk, S, tid);
     vst.load(Vb, p.ldv, S, tid);
     kst.write(smem, tid);
-    vst.write(smem + 2 * KB, tid);
+    vst.write(smem + 2 * TB, tid);
   }
   __syncthreads();
   // hipcc's waitcnt pass keeps loop-carried "pending load" state for the Q fragments and would drain
@@ -166,79 +201,78 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
   for (int j = 0; j < ntiles; ++j) {
     const int kv0 = j * 64;
-    const char* sK = smem + (j & 1) * KB;
-    const char* sV = smem + 2 * KB + (j & 1) * VB;
+    const char* sK = smem + (j & 1) * TB;
+    const char* sV = smem + 2 * TB + (j & 1) * TB;
     const bool more = (j + 1 < ntiles);
     if (more) {        // prefetch tile j+1 into registers; the loads fly under this tile's MFMAs
       kst.load(Kb + (long long)(kv0 + 64) * p.ldk, p.ldk, S - kv0 - 64, tid);
       vst.load(Vb + (long long)(kv0 + 64) * p.ldv, p.ldv, S - kv0 - 64, tid);
     }
     if (!(CAUSAL && kv0 > qw0 + 31)) {      // wave-uniform: something visible to this wave
-
-    f32x4 s[2][4];
+      f32x4 s[2][4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 kf = read_rows<HD>(sK, nt * 16 + li, ks * 4 + g);
+        for (int nt = 0; nt < 4; ++nt) {
+          const bf16x8 kf = read_rows<HD, 0>(sK, nt * 16 + li, ks * 4 + g);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)     // first k-step accumulates onto a loop-invariant zero (no per-tile clears)
-          s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : s[qt][nt], 0, 0, 0);
-      }
-    const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
-    bf16x8 pf[2][2];
+          for (int qt = 0; qt < 2; ++qt)     // first k-step accumulates onto a loop-invariant zero (no per-tile clears)
+            s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : s[qt][nt], 0, 0, 0);
+        }
+      const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
+      bf16x8 pf[2][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int q = qw0 + qt * 16 + li;
-      float mx = -INFINITY;                       // running max is kept in RAW score units; c > 0
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = qw0 + qt * 16 + li;
+        float mx = -INFINITY;                       // running max is kept in RAW score units; c > 0
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[qt][nt][r];
-          if (need_mask) {
-            const int key = kv0 + nt * 16 + g * 4 + r;
-            if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
-            s[qt][nt][r] = v;
+          for (int r = 0; r < 4; ++r) {
+            float v = s[qt][nt][r];
+            if (need_mask) {
+              const int key = kv0 + nt * 16 + g * 4 + r;
+              if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
+              s[qt][nt][r] = v;
+            }
+            mx = fmaxf(mx, v);
           }
-          mx = fmaxf(mx, v);
+        mx = xmax16(mx);
+        const float mnew = fmaxf(mrun[qt], mx);
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c);
+        const float nmc = -msafe * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][nt][r], c, nmc));
+            s[qt][nt][r] = pv;
+            rs += pv;
+          }
+        rs = xsum16(rs);
+        lrun[qt] = lrun[qt] * alpha + rs;
+        mrun[qt] = mnew;
+        if (!__all(alpha == 1.f)) {                  // wave-uniform: most tiles do not move any row max
+#pragma unroll
+          for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
         }
-      mx = xmax16(mx);
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c);
-      const float nmc = -msafe * c;
-      float rs = 0.f;
+        pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
+        pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
+      }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][nt][r], c, nmc));
-          s[qt][nt][r] = pv;
-          rs += pv;
+        for (int d = 0; d < DT; ++d) {
+          const bf16x8 vf = read_tr<HD, 2>(sV, d, st, lane);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
         }
-      rs = xsum16(rs);
-      lrun[qt] = lrun[qt] * alpha + rs;
-      mrun[qt] = mnew;
-      if (!__all(alpha == 1.f)) {                  // wave-uniform: most tiles do not move any row max
-#pragma unroll
-        for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
-      }
-      pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
-      pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const bf16x8 vf = read_tr<HD>(sV, d, st, lane);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
-      }
     }   // active wave
     if (more) {
-      kst.write(smem + ((j + 1) & 1) * KB, tid);
-      vst.write(smem + 2 * KB + ((j + 1) & 1) * VB, tid);
+      kst.write(smem + ((j + 1) & 1) * TB, tid);
+      vst.write(smem + 2 * TB + ((j + 1) & 1) * TB, tid);
     }
     __syncthreads();
   }
@@ -248,23 +282,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const int q = qw0 + qt * 16 + li;
     if (q >= S) continue;
     const float inv = lrun[qt] > 0.f ? 1.f / lrun[qt] : 0.f;
-    bf16_t* op = p.O + (tok0 + q) * p.ldo + h * HD + g * 16;
-#pragma unroll
-    for (int sp = 0; sp < HD / 64; ++sp) {
-      u32x4 w0, w1;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        w0[k * 2] = pack2bf(o[qt][sp * 4 + k][0] * inv, o[qt][sp * 4 + k][1] * inv);
-        w0[k * 2 + 1] = pack2bf(o[qt][sp * 4 + k][2] * inv, o[qt][sp * 4 + k][3] * inv);
-        w1[k * 2] = pack2bf(o[qt][sp * 4 + 2 + k][0] * inv, o[qt][sp * 4 + 2 + k][1] * inv);
-        w1[k * 2 + 1] = pack2bf(o[qt][sp * 4 + 2 + k][2] * inv, o[qt][sp * 4 + 2 + k][3] * inv);
-      }
-      *(u32x4*)(op + sp * 64) = w0;
-      *(u32x4*)(op + sp * 64 + 8) = w1;
-    }
+    store_rows16<HD>(p.O + (tok0 + q) * p.ldo + h * HD + g * 16, o[qt], inv);
     if (g == 0 && p.LSE)
       p.LSE[((long long)b * p.nh + h) * S + q] =
           (lrun[qt] > 0.f) ? mrun[qt] * p.scale + __builtin_amdgcn_logf(lrun[qt]) * 0.6931471805599453f : -INFINITY;
+  }
+}
+
+// Causal work per query block grows linearly with its index: every workgroup takes the pair
+// (nqb-1-x, x), so all workgroups carry the same number of K/V tiles and the launch has no ragged tail.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(NTHR, 2) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (CAUSAL) {
+    const int nqb = (p.S + NWAVE * 32 - 1) / (NWAVE * 32), x = blockIdx.x;
+    const int npass = (2 * x + 1 < nqb) ? 2 : 1;
+#pragma nounroll
+    for (int pass = 0; pass < npass; ++pass)
+      attn_fwd_block<HD, true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.y, blockIdx.z);
+  } else {
+    attn_fwd_block<HD, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
   }
 }
 
@@ -291,25 +328,25 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ============================================================================ backward: dQ
-// One block = 128 queries of one (b, head); loops over K/V tiles of 64 keys (same range as forward).
+// One workgroup = NWAVE*32 queries of one (b, head); loops over K/V tiles of 64 keys (same range as forward).
+// Q fragments live in registers; the workgroup's dO rows are staged ONCE in LDS (fragments re-read per tile
+// with ds_read_b128), so the only global loads inside the loop are the register-staged K/V prefetch.
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
-  constexpr int KS = HD / 32, DT = HD / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + 64 * HD * 2;
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void attn_bwd_dq_block(const AttnP& p, char* smem, int qb, int h, int b) {
+  constexpr int KS = HD / 32, DT = HD / 16, QB = NWAVE * 32;
+  constexpr int TB = 64 * HD * 2;                       // layout: K[2], V[2], dO[QB rows]
+  char* sdO = smem + 4 * TB;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));     // per-lane addresses are re-derived per pass, not hoisted (and spilled) across passes
+  const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
+  const int hk = h / p.group;
   const int S = p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
-  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const int q0 = qb * QB, qw0 = q0 + wave * 32;
   const long long tok0 = (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
 
-  // Q fragments stay resident; dO fragments are re-read per K/V tile (L1/L2 hits) to stay
-  // under 256 VGPRs without spilling.
   bf16x8 qf[2][KS];
   float lse2[2], dl[2];
 #pragma unroll
@@ -332,99 +369,125 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
   const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
   const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + HD) * 2), 0x00020000);
-  const int kv_end = CAUSAL ? min(q0 + 128, len) : len;
+  const int kv_end = CAUSAL ? min(q0 + QB, len) : len;
   const int ntiles = (kv_end + 63) >> 6;
+
+  RStage<HD, 1> kst;        // K: b128 (S^T) and tr (dQ^T) reads
+  RStage<HD, 0> vst;        // V: b128 only
+  {
+    RStage<HD, 0, QB> dst;  // dO rows of this workgroup, once
+    dst.load(p.dO + (tok0 + q0) * p.lddo + h * HD, p.lddo, S - q0, tid);
+    dst.write(sdO, tid);
+  }
+  if (ntiles > 0) {
+    kst.load(Kb, p.ldk, S, tid);
+    vst.load(Vb, p.ldv, S, tid);
+    kst.write(smem, tid);
+    vst.write(smem + 2 * TB, tid);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+    asm volatile("" : "+v"(lse2[qt]), "+v"(dl[qt]));
+  }
 
   for (int j = 0; j < ntiles; ++j) {
     const int kv0 = j * 64;
-    __syncthreads();
-    stage_rows<HD>(rsK, sK, wave, lane, kv0, S, p.ldk);
-    stage_rows<HD>(rsV, sV, wave, lane, kv0, S, p.ldv);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (CAUSAL && kv0 > qw0 + 31) continue;
-
-    // q-tiles are processed one after the other to keep S / dP live ranges at 32 registers
-    bf16x8 dsf[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      f32x4 s[4], dp[4];
-      const int q = qw0 + qt * 16 + li;
-      const bf16_t* dop = p.dO + (tok0 + min(q, S - 1)) * p.lddo + h * HD + g * 8;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 dofr = *(const bf16x8*)(dop + ks * 32);   // rows q >= S are masked below
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const bf16x8 kf = read_rows<HD>(sK, nt * 16 + li, ks * 4 + g);
-          const bf16x8 vf = read_rows<HD>(sV, nt * 16 + li, ks * 4 + g);
-          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[nt], 0, 0, 0);
-          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dofr, dp[nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + nt * 16 + g * 4 + r;
-          float pv = __builtin_amdgcn_exp2f(s[nt][r] * c - lse2[qt]);
-          if (key >= len || (CAUSAL && key > q) || q >= S) pv = 0.f;
-          s[nt][r] = pv * (dp[nt][r] - dl[qt]);
-        }
-      dsf[qt][0] = pack_frag(s[0], s[1]);
-      dsf[qt][1] = pack_frag(s[2], s[3]);
+    const char* sK = smem + (j & 1) * TB;
+    const char* sV = smem + 2 * TB + (j & 1) * TB;
+    const bool more = (j + 1 < ntiles);
+    if (more) {
+      kst.load(Kb + (long long)(kv0 + 64) * p.ldk, p.ldk, S - kv0 - 64, tid);
+      vst.load(Vb + (long long)(kv0 + 64) * p.ldv, p.ldv, S - kv0 - 64, tid);
     }
+    if (!(CAUSAL && kv0 > qw0 + 31)) {
+      // q-tiles are processed one after the other to keep S / dP live ranges at 32 registers
+      bf16x8 dsf[2][2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 s[4], dp[4];
+        const int q = qw0 + qt * 16 + li;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const bf16x8 ktf = read_tr<HD>(sK, d, st, lane);
+        for (int nt = 0; nt < 4; ++nt) { s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][st], dq[qt][d], 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 dofr = read_rows<HD, 0>(sdO, wave * 32 + qt * 16 + li, ks * 4 + g);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const bf16x8 kf = read_rows<HD, 1>(sK, nt * 16 + li, ks * 4 + g);
+            const bf16x8 vf = read_rows<HD, 0>(sV, nt * 16 + li, ks * 4 + g);
+            s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[nt], 0, 0, 0);
+            dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dofr, dp[nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + nt * 16 + g * 4 + r;
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nt][r], c, -lse2[qt]));
+            if (key >= len || (CAUSAL && key > q) || q >= S) pv = 0.f;
+            s[nt][r] = pv * (dp[nt][r] - dl[qt]);
+          }
+        dsf[qt][0] = pack_frag(s[0], s[1]);
+        dsf[qt][1] = pack_frag(s[2], s[3]);
       }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16x8 ktf = read_tr<HD, 1>(sK, d, st, lane);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][st], dq[qt][d], 0, 0, 0);
+        }
+    }
+    if (more) {
+      kst.write(smem + ((j + 1) & 1) * TB, tid);
+      vst.write(smem + 2 * TB + ((j + 1) & 1) * TB, tid);
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qw0 + qt * 16 + li;
     if (q >= S) continue;
-    bf16_t* op = p.dQ + (tok0 + q) * p.lddq + h * HD + g * 16;
-#pragma unroll
-    for (int sp = 0; sp < HD / 64; ++sp) {
-      u32x4 w0, w1;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        w0[k * 2] = pack2bf(dq[qt][sp * 4 + k][0] * p.scale, dq[qt][sp * 4 + k][1] * p.scale);
-        w0[k * 2 + 1] = pack2bf(dq[qt][sp * 4 + k][2] * p.scale, dq[qt][sp * 4 + k][3] * p.scale);
-        w1[k * 2] = pack2bf(dq[qt][sp * 4 + 2 + k][0] * p.scale, dq[qt][sp * 4 + 2 + k][1] * p.scale);
-        w1[k * 2 + 1] = pack2bf(dq[qt][sp * 4 + 2 + k][2] * p.scale, dq[qt][sp * 4 + 2 + k][3] * p.scale);
-      }
-      *(u32x4*)(op + sp * 64) = w0;
-      *(u32x4*)(op + sp * 64 + 8) = w1;
+    store_rows16<HD>(p.dQ + (tok0 + q) * p.lddq + h * HD + g * 16, dq[qt], p.scale);
+  }
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(NTHR, 2) void attn_bwd_dq_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (CAUSAL) {                 // balanced pairs, as in forward
+    const int nqb = (p.S + NWAVE * 32 - 1) / (NWAVE * 32), x = blockIdx.x;
+    const int npass = (2 * x + 1 < nqb) ? 2 : 1;
+#pragma nounroll
+    for (int pass = 0; pass < npass; ++pass) {
+      attn_bwd_dq_block<HD, true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.y, blockIdx.z);
+      __syncthreads();                    // the dO rows of a block are read until its last tile
     }
+  } else {
+    attn_bwd_dq_block<HD, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
   }
 }
 
 // ============================================================================ backward: dK, dV
-// One block = 64 keys of one (b, kv head): 4 waves x 16 keys; loops over the q heads of the GQA
-// group and over Q / dO tiles of 64 queries.
+// One workgroup = NWAVE*16 keys of one (b, kv head); loops over the q heads of the GQA group and over
+// Q / dO tiles of 64 queries (register-staged, double-buffered, together with their lse / delta rows).
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
-  constexpr int KS = HD / 32, DT = HD / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;
-  char* sdO = smem + 64 * HD * 2;
-  float* sLse = (float*)(smem + 2 * 64 * HD * 2);
-  float* sDl = sLse + 64;
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void attn_bwd_dkv_block(const AttnP& p, char* smem, int kb, int hk, int b) {
+  constexpr int KS = HD / 32, DT = HD / 16, KBLK = NWAVE * 16;
+  constexpr int TB = 64 * HD * 2;                       // layout: Q[2], dO[2], {lse[64], delta[64]}[2]
+  float* sLD = (float*)(smem + 4 * TB);
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kb = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int S = p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
-  const int k0 = kb * 64, kw0 = k0 + wave * 16;
+  const int k0 = kb * KBLK, kw0 = k0 + wave * 16;
   const int key = kw0 + li;
   const long long tok0 = (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
@@ -446,27 +509,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 
   const int nq = (S + 63) >> 6;
   const int qt_first = CAUSAL ? (k0 >> 6) : 0;
-  const bool live_block = k0 < len;
+  const int per_head = nq - qt_first;
+  const int total = (k0 < len) ? per_head * p.group : 0;       // (head-in-group, q tile) pairs, flattened
 
-  for (int hh = 0; hh < p.group && live_block; ++hh) {
-    const int h = hk * p.group + hh;
-    const bf16_t* Qb = p.Q + tok0 * p.ldq + h * HD;
-    const bf16_t* dOb = p.dO + tok0 * p.lddo + h * HD;
-    __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)(((long long)(S - 1) * p.ldq + HD) * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)dOb, 0, (int)(((long long)(S - 1) * p.lddo + HD) * 2), 0x00020000);
-    const float* lseb = p.LSE + ((long long)b * p.nh + h) * S;
-    const float* dlb = p.Delta + ((long long)b * p.nh + h) * S;
-    for (int j = qt_first; j < nq; ++j) {
-      const int q0 = j * 64;
-      __syncthreads();
-      stage_rows<HD>(rsQ, sQ, wave, lane, q0, S, p.ldq);
-      stage_rows<HD>(rsO, sdO, wave, lane, q0, S, p.lddo);
-      if (tid < 64) sLse[tid] = (q0 + tid < S) ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
-      else if (tid < 128) sDl[tid - 64] = (q0 + tid - 64 < S) ? dlb[q0 + tid - 64] : 0.f;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (CAUSAL && q0 + 63 < kw0) continue;     // every query of the tile precedes this wave's keys
+  RStage<HD, 1> qst, ost;    // Q and dO tiles: b128 (S, dP) and tr (dK^T, dV^T) reads
+  float ld_reg = 0.f;        // one lse (threads 0..63) or delta (64..127) value of the tile being staged
+  auto prefetch = [&](int it) {
+    const int hh = it / per_head, j = qt_first + it - hh * per_head;
+    const int h = hk * p.group + hh, q0 = j * 64;
+    qst.load(p.Q + (tok0 + q0) * p.ldq + h * HD, p.ldq, S - q0, tid);
+    ost.load(p.dO + (tok0 + q0) * p.lddo + h * HD, p.lddo, S - q0, tid);
+    const long long si = ((long long)b * p.nh + h) * S;
+    if (tid < 64) ld_reg = (q0 + tid < S) ? p.LSE[si + q0 + tid] * 1.4426950408889634f : 0.f;
+    else if (tid < 128) ld_reg = (q0 + tid - 64 < S) ? p.Delta[si + q0 + tid - 64] : 0.f;
+  };
+  auto commit = [&](int buf) {
+    qst.write(smem + buf * TB, tid);
+    ost.write(smem + 2 * TB + buf * TB, tid);
+    if (tid < 128) sLD[buf * 128 + tid] = ld_reg;
+  };
+  if (total > 0) { prefetch(0); commit(0); }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
 
+  for (int it = 0; it < total; ++it) {
+    const int hh = it / per_head, j = qt_first + it - hh * per_head;
+    const int q0 = j * 64;
+    const char* sQ = smem + (it & 1) * TB;
+    const char* sdO = smem + 2 * TB + (it & 1) * TB;
+    const float* sLse = sLD + (it & 1) * 128;
+    const float* sDl = sLse + 64;
+    const bool more = (it + 1 < total);
+    if (more) prefetch(it + 1);
+    if (!(CAUSAL && q0 + 63 < kw0)) {          // not every query of the tile precedes this wave's keys
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) { s[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -474,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const bf16x8 qfr = read_rows<HD>(sQ, t * 16 + li, ks * 4 + g);
-          const bf16x8 dofr = read_rows<HD>(sdO, t * 16 + li, ks * 4 + g);
+          const bf16x8 qfr = read_rows<HD, 1>(sQ, t * 16 + li, ks * 4 + g);
+          const bf16x8 dofr = read_rows<HD, 1>(sdO, t * 16 + li, ks * 4 + g);
           s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[ks], s[t], 0, 0, 0);
           dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[ks], dp[t], 0, 0, 0);
         }
@@ -487,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q0 + t * 16 + g * 4 + r;
-          float pv = __builtin_amdgcn_exp2f(s[t][r] * c - l4[r]);
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -l4[r]));
           if (q >= S || key >= len || (CAUSAL && key > q)) pv = 0.f;
           s[t][r] = pv;
           dp[t][r] = pv * (dp[t][r] - d4[r]);
@@ -497,41 +573,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnP p) {
       const bf16x8 ds0 = pack_frag(dp[0], dp[1]), ds1 = pack_frag(dp[2], dp[3]);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16x8 o0 = read_tr<HD>(sdO, d, 0, lane), o1 = read_tr<HD>(sdO, d, 1, lane);
+        const bf16x8 o0 = read_tr<HD, 1>(sdO, d, 0, lane), o1 = read_tr<HD, 1>(sdO, d, 1, lane);
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[d], 0, 0, 0);
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[d], 0, 0, 0);
-        const bf16x8 t0 = read_tr<HD>(sQ, d, 0, lane), t1 = read_tr<HD>(sQ, d, 1, lane);
+        const bf16x8 t0 = read_tr<HD, 1>(sQ, d, 0, lane), t1 = read_tr<HD, 1>(sQ, d, 1, lane);
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, ds0, dk[d], 0, 0, 0);
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, ds1, dk[d], 0, 0, 0);
       }
     }
+    if (more) commit((it + 1) & 1);
+    __syncthreads();
   }
   if (key < S) {
-    bf16_t* kp = p.dK + (tok0 + key) * p.lddk + hk * HD + g * 16;
-    bf16_t* vp = p.dV + (tok0 + key) * p.lddv + hk * HD + g * 16;
-#pragma unroll
-    for (int sp = 0; sp < HD / 64; ++sp) {
-      u32x4 a0, a1, b0, b1;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        a0[k * 2] = pack2bf(dk[sp * 4 + k][0] * p.scale, dk[sp * 4 + k][1] * p.scale);
-        a0[k * 2 + 1] = pack2bf(dk[sp * 4 + k][2] * p.scale, dk[sp * 4 + k][3] * p.scale);
-        a1[k * 2] = pack2bf(dk[sp * 4 + 2 + k][0] * p.scale, dk[sp * 4 + 2 + k][1] * p.scale);
-        a1[k * 2 + 1] = pack2bf(dk[sp * 4 + 2 + k][2] * p.scale, dk[sp * 4 + 2 + k][3] * p.scale);
-        b0[k * 2] = pack2bf(dv[sp * 4 + k][0], dv[sp * 4 + k][1]);
-        b0[k * 2 + 1] = pack2bf(dv[sp * 4 + k][2], dv[sp * 4 + k][3]);
-        b1[k * 2] = pack2bf(dv[sp * 4 + 2 + k][0], dv[sp * 4 + 2 + k][1]);
-        b1[k * 2 + 1] = pack2bf(dv[sp * 4 + 2 + k][2], dv[sp * 4 + 2 + k][3]);
-      }
-      *(u32x4*)(kp + sp * 64) = a0; *(u32x4*)(kp + sp * 64 + 8) = a1;
-      *(u32x4*)(vp + sp * 64) = b0; *(u32x4*)(vp + sp * 64 + 8) = b1;
-    }
+    store_rows16<HD>(p.dK + (tok0 + key) * p.lddk + hk * HD + g * 16, dk, p.scale);
+    store_rows16<HD>(p.dV + (tok0 + key) * p.lddv + hk * HD + g * 16, dv, 1.f);
+  }
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(NTHR, 2) void attn_bwd_dkv_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (CAUSAL) {                 // early key blocks see every query tile, late ones almost none: pair them
+    const int nkb = (p.S + NWAVE * 16 - 1) / (NWAVE * 16), x = blockIdx.x;
+    const int npass = (2 * x + 1 < nkb) ? 2 : 1;
+#pragma nounroll
+    for (int pass = 0; pass < npass; ++pass)
+      attn_bwd_dkv_block<HD, true>(p, smem, pass ? nkb - 1 - x : x, blockIdx.y, blockIdx.z);
+  } else {
+    attn_bwd_dkv_block<HD, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
   }
 }
 
 template <typename KT>
-static int set_lds(KT kern, int bytes) {
-  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+static void set_lds(KT kern, int bytes) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 static int check_common(int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv) {
@@ -559,12 +634,14 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = lse;
   p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
-  const dim3 grid((S + 127) / 128, nh, B);
+  constexpr int QB = NWAVE * 32;
+  const int nqb = (S + QB - 1) / QB;
+  const dim3 grid(causal ? (nqb + 1) / 2 : nqb, nh, B);
   const int lds = 4 * 64 * hd * 2;
-  if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), lds, stream, p); }
-  else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), lds, stream, p); }
-  else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, stream, p); }
-  else { set_lds(attn_fwd_kernel<64, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), lds, stream, p); }
+  if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(NTHR), lds, stream, p); }
+  else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(NTHR), lds, stream, p); }
+  else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(NTHR), lds, stream, p); }
+  else { set_lds(attn_fwd_kernel<64, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(NTHR), lds, stream, p); }
   return lmod_launch_status();
 }
 
@@ -588,15 +665,17 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo);
-  const dim3 gq((S + 127) / 128, nh, B), gk((S + 63) / 64, nkv, B);
-  const int lds_q = 2 * 64 * hd * 2;
-  const int lds_k = 2 * 64 * hd * 2 + 512;
+  constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;
+  const int nqb = (S + QB - 1) / QB, nkb = (S + KBLK - 1) / KBLK;
+  const dim3 gq(causal ? (nqb + 1) / 2 : nqb, nh, B), gk(causal ? (nkb + 1) / 2 : nkb, nkv, B);
+  const int lds_q = 4 * 64 * hd * 2 + QB * hd * 2;
+  const int lds_k = 4 * 64 * hd * 2 + 1024;
 #define LAUNCH_BWD(HDV, CZ)                                                                                        \
   do {                                                                                                             \
     set_lds(attn_bwd_dq_kernel<HDV, CZ>, lds_q);                                                                   \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, CZ>), gq, dim3(256), lds_q, stream, p);                            \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, CZ>), gq, dim3(NTHR), lds_q, stream, p);                           \
     set_lds(attn_bwd_dkv_kernel<HDV, CZ>, lds_k);                                                                  \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, CZ>), gk, dim3(256), lds_k, stream, p);                           \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, CZ>), gk, dim3(NTHR), lds_k, stream, p);                          \
   } while (0)
   if (hd == 128 && causal) LAUNCH_BWD(128, true);
   else if (hd == 128) LAUNCH_BWD(128, false);
