@@ -40,6 +40,7 @@ struct AttnP {
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 // ---- LDS tile image: [rows = tokens][HD bf16], 16-byte chunks XOR-swizzled per row.  Swizzles for HD 128:
 //  SW 0  key = row & 15                      conflict-free for ds_read_b128 operand reads (rows = lane&15);
@@ -145,29 +146,29 @@ __device__ __forceinline__ void store_rows16(bf16_t* dst, const f32x4 (&acc)[HD 
 }
 
 // ============================================================================ forward
+// Schedule: the 8 waves form two groups (waves w and w+4 share a SIMD).  A K/V tile is processed in two
+// barrier intervals, X = [QK^T MFMAs | softmax of query tile 0] and Y = [softmax of query tile 1 | PV MFMAs];
+// group 1 runs one interval behind group 0 (it passes one extra barrier up front), so on every SIMD one wave
+// is in its MFMA half while the other is in its VALU half instead of both fighting for the same pipe.
+// Tile j+1 is loaded to registers by everybody in interval 2j and written to LDS at the end of interval 2j+1.
+// raw barrier: waits for this wave's LDS traffic only — the register prefetch (vmcnt) stays in flight across it
+#define ATT_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 template <int HD, bool CAUSAL>
 __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int qb, int h, int b) {
   constexpr int KS = HD / 32, DT = HD / 16, QB = NWAVE * 32;
-  constexpr int TB = 64 * HD * 2;                       // tile bytes; layout: K[2], V[2]
+  constexpr int TB = 64 * HD * 2;                       // tile bytes; layout: K[2], V[2], Q[QB rows]
+  char* sQ = smem + 4 * TB;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));     // per-lane addresses are re-derived per pass, not hoisted (and spilled) across passes
   const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = (NWAVE == 8) ? (wave >> 2) : 0;
   const int hk = h / p.group;
   const int S = p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
   const int q0 = qb * QB, qw0 = q0 + wave * 32;
   const long long tok0 = (long long)b * S;
 
-  bf16x8 qf[2][KS];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int q = qw0 + qt * 16 + li;
-      if (q < S) qf[qt][ks] = *(const bf16x8*)(p.Q + (tok0 + q) * p.ldq + h * HD + ks * 32 + g * 8);
-      else qf[qt][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
   f32x4 o[2][DT];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
@@ -185,82 +186,104 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
 
   RStage<HD, 0> kst;        // K: b128 reads only
   RStage<HD, 2> vst;        // V: tr reads only
-  if (ntiles > 0) {
-    kst.load(Kb, p.ldk, S, tid);
-    vst.load(Vb, p.ldv, S, tid);
-    kst.write(smem, tid);
-    vst.write(smem + 2 * TB, tid);
+  auto prefetch = [&](int t) {
+    kst.load(Kb + (long long)t * 64 * p.ldk, p.ldk, S - t * 64, tid);
+    vst.load(Vb + (long long)t * 64 * p.ldv, p.ldv, S - t * 64, tid);
+  };
+  auto commit = [&](int t) {
+    kst.write(smem + (t & 1) * TB, tid);
+    vst.write(smem + 2 * TB + (t & 1) * TB, tid);
+  };
+  {                         // this workgroup's Q rows, once (operand fragments are re-read per K tile)
+    RStage<HD, 0, QB> qst;
+    qst.load(p.Q + (tok0 + q0) * p.ldq + h * HD, p.ldq, S - q0, tid);
+    qst.write(sQ, tid);
   }
+  if (ntiles > 0) { prefetch(0); commit(0); }
   __syncthreads();
-  // hipcc's waitcnt pass keeps loop-carried "pending load" state for the Q fragments and would drain
-  // vmcnt(0) (killing the prefetch overlap) at their first use in every iteration: make them opaque.
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+  if (grp == 1) {           // interval 0 of group 0: group 1 only fetches tile 1
+    if (1 < ntiles) prefetch(1);
+    ATT_BARRIER();
+  }
 
   for (int j = 0; j < ntiles; ++j) {
     const int kv0 = j * 64;
     const char* sK = smem + (j & 1) * TB;
     const char* sV = smem + 2 * TB + (j & 1) * TB;
-    const bool more = (j + 1 < ntiles);
-    if (more) {        // prefetch tile j+1 into registers; the loads fly under this tile's MFMAs
-      kst.load(Kb + (long long)(kv0 + 64) * p.ldk, p.ldk, S - kv0 - 64, tid);
-      vst.load(Vb + (long long)(kv0 + 64) * p.ldv, p.ldv, S - kv0 - 64, tid);
-    }
-    if (!(CAUSAL && kv0 > qw0 + 31)) {      // wave-uniform: something visible to this wave
-      f32x4 s[2][4];
+    const bool active = !(CAUSAL && kv0 > qw0 + 31);      // wave-uniform: something visible to this wave
+    const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
+    f32x4 s[2][4];
+    bf16x8 pf[2][2];
+    // online softmax of one 16-query tile; the masked flavour only runs on diagonal / padded tiles so the
+    // steady state carries no compares or selects
+    auto softmax = [&](auto masked, const int qt) {
+      constexpr bool MASKED = decltype(masked)::value;
+      const int q = qw0 + qt * 16 + li;
+      float mx = -INFINITY;                       // running max is kept in RAW score units; c > 0
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[qt][nt][r];
+          if constexpr (MASKED) {
+            const int key = kv0 + nt * 16 + g * 4 + r;
+            if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
+            s[qt][nt][r] = v;
+          }
+          mx = fmaxf(mx, v);
+        }
+      mx = xmax16(mx);
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c);
+      const float nmc = -msafe * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][nt][r], c, nmc));
+          s[qt][nt][r] = pv;
+          rs += pv;
+        }
+      rs = xsum16(rs);
+      lrun[qt] = lrun[qt] * alpha + rs;
+      mrun[qt] = mnew;
+      if (!__all(alpha == 1.f)) {                  // wave-uniform: most tiles do not move any row max
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
+      }
+      pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
+      pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
+    };
+
+    // ---------------- interval X
+    if (grp == 0 && j + 1 < ntiles) prefetch(j + 1);
+    if (active) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 q0f = read_rows<HD, 0>(sQ, wave * 32 + li, ks * 4 + g);
+        const bf16x8 q1f = read_rows<HD, 0>(sQ, wave * 32 + 16 + li, ks * 4 + g);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const bf16x8 kf = read_rows<HD, 0>(sK, nt * 16 + li, ks * 4 + g);
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)     // first k-step accumulates onto a loop-invariant zero (no per-tile clears)
-            s[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : s[qt][nt], 0, 0, 0);
+          // first k-step accumulates onto a loop-invariant zero (no per-tile clears)
+          s[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q0f, ks == 0 ? zero4 : s[0][nt], 0, 0, 0);
+          s[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q1f, ks == 0 ? zero4 : s[1][nt], 0, 0, 0);
         }
-      const bool need_mask = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > qw0);
-      bf16x8 pf[2][2];
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int q = qw0 + qt * 16 + li;
-        float mx = -INFINITY;                       // running max is kept in RAW score units; c > 0
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = s[qt][nt][r];
-            if (need_mask) {
-              const int key = kv0 + nt * 16 + g * 4 + r;
-              if (key >= len || (CAUSAL && key > q)) v = -INFINITY;
-              s[qt][nt][r] = v;
-            }
-            mx = fmaxf(mx, v);
-          }
-        mx = xmax16(mx);
-        const float mnew = fmaxf(mrun[qt], mx);
-        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c);
-        const float nmc = -msafe * c;
-        float rs = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][nt][r], c, nmc));
-            s[qt][nt][r] = pv;
-            rs += pv;
-          }
-        rs = xsum16(rs);
-        lrun[qt] = lrun[qt] * alpha + rs;
-        mrun[qt] = mnew;
-        if (!__all(alpha == 1.f)) {                  // wave-uniform: most tiles do not move any row max
-#pragma unroll
-          for (int d = 0; d < DT; ++d) o[qt][d] *= alpha;
-        }
-        pf[qt][0] = pack_frag(s[qt][0], s[qt][1]);
-        pf[qt][1] = pack_frag(s[qt][2], s[qt][3]);
+        __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting every operand read of the tile (spills)
       }
+      __builtin_amdgcn_s_setprio(0);
+      if (need_mask) softmax(BoolTag<true>{}, 0); else softmax(BoolTag<false>{}, 0);
+    }
+    if (grp == 1 && j + 1 < ntiles) commit(j + 1);
+    ATT_BARRIER();
+    // ---------------- interval Y
+    if (grp == 1 && j + 2 < ntiles) prefetch(j + 2);
+    if (active) {
+      if (need_mask) softmax(BoolTag<true>{}, 1); else softmax(BoolTag<false>{}, 1);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -268,14 +291,14 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
           const bf16x8 vf = read_tr<HD, 2>(sV, d, st, lane);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
+          if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-    }   // active wave
-    if (more) {
-      kst.write(smem + ((j + 1) & 1) * TB, tid);
-      vst.write(smem + 2 * TB + ((j + 1) & 1) * TB, tid);
+      __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
+    if (grp == 0 && j + 1 < ntiles) commit(j + 1);
+    ATT_BARRIER();
   }
+  if (grp == 0 && NWAVE == 8) ATT_BARRIER();      // group 0 matches group 1's extra barrier
 
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -298,8 +321,10 @@ __global__ __launch_bounds__(NTHR, 2) void attn_fwd_kernel(AttnP p) {
     const int nqb = (p.S + NWAVE * 32 - 1) / (NWAVE * 32), x = blockIdx.x;
     const int npass = (2 * x + 1 < nqb) ? 2 : 1;
 #pragma nounroll
-    for (int pass = 0; pass < npass; ++pass)
+    for (int pass = 0; pass < npass; ++pass) {
       attn_fwd_block<HD, true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.y, blockIdx.z);
+      __syncthreads();                    // the Q rows of a block are read until its last tile
+    }
   } else {
     attn_fwd_block<HD, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
   }
@@ -637,7 +662,7 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   constexpr int QB = NWAVE * 32;
   const int nqb = (S + QB - 1) / QB;
   const dim3 grid(causal ? (nqb + 1) / 2 : nqb, nh, B);
-  const int lds = 4 * 64 * hd * 2;
+  const int lds = 4 * 64 * hd * 2 + QB * hd * 2;
   if (hd == 128 && causal) { set_lds(attn_fwd_kernel<128, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(NTHR), lds, stream, p); }
   else if (hd == 128) { set_lds(attn_fwd_kernel<128, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(NTHR), lds, stream, p); }
   else if (causal) { set_lds(attn_fwd_kernel<64, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(NTHR), lds, stream, p); }
