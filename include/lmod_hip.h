@@ -29,7 +29,8 @@ extern "C" {
  * :1163 (lm_head); multimodal_projector/builder.py:57-61; HF CLIP linears + patch conv
  * (multimodal_encoder/clip_encoder.py:54).  With m_valid/k_valid (device int[batch]) it is the
  * grouped GEMM over DeepSpeed MoE capacity slabs (deepspeed.moe.experts; llava_qwen2_moe.py:536-546).
- * act: 0 none, 1 exact GELU, 2 quick_gelu.  out_f32: C is fp32.  accumulate: C += .
+ * act: 0 none, 1 exact GELU, 2 quick_gelu, 3 fused SwiGLU (B rows interleaved gate/up in blocks of 8;
+ *      C is bf16 with N/2 columns = silu(gate) * up, N % 16 == 0).  out_f32: C is fp32.  accumulate: C += .
  * Requires K % 8 == 0, lda/ldb % 8 == 0, A/B 16-byte aligned. */
 int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
                       int ldc, int batch, long long strideA, long long strideB, long long strideC, const int* m_valid,

@@ -26,7 +26,7 @@ struct GemmP {
   int M, N, K, lda, ldb, ldc;
   int batch; long long sA, sB, sC;
   const int* m_valid; const int* k_valid;
-  int act;         // 0 none, 1 exact GELU, 2 quick_gelu
+  int act;         // 0 none, 1 exact GELU, 2 quick_gelu, 3 SwiGLU over (gate, up) column blocks of 8 -> C has N/2 columns
   int out_f32;     // 0: bf16 C, 1: f32 C
   int accumulate;  // C += result (read-modify-write)
   int vec_ok;      // C pointer / ldc allow 16-byte vector stores
@@ -34,6 +34,21 @@ struct GemmP {
 };
 
 #define GEMM_OOB 0x80000000u
+
+// act 3: the weight rows are interleaved in blocks of 8 (g0..7, u0..7, g8..15, u8..15, ...), so the 16 contiguous
+// output columns a lane owns are 8 gate values and their 8 up values: silu(gate) * up leaves as ONE 16-byte store
+// of the half-width activation (same roundings as the separate kernel: bf16 gate/up, bf16 silu, bf16 product;
+// reference qwen2/modeling_qwen2.py:186-187).
+__device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float g0 = bfround(v[2 * k]), g1 = bfround(v[2 * k + 1]);
+    const float s0 = bfround(g0 / (1.f + __expf(-g0))), s1 = bfround(g1 / (1.f + __expf(-g1)));
+    o[k] = pack2bf(s0 * bfround(v[8 + 2 * k]), s1 * bfround(v[8 + 2 * k + 1]));
+  }
+  return o;
+}
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
@@ -203,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
+    if (p.act == 3) {          // N % 16 == 0 and 16-byte aligned C are checked on the host
+      if (cb < p.N) *(u32x4*)((bf16_t*)Cb + (long long)row * p.ldc + (cb >> 1)) = swiglu_pairs(v);
+      continue;
+    }
     if (p.act) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
@@ -448,6 +467,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
+    if (p.act == 3) {
+      if (cb < p.N) *(u32x4*)((bf16_t*)Cb + (long long)row * p.ldc + (cb >> 1)) = swiglu_pairs(v);
+      continue;
+    }
     if (p.act) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
@@ -532,9 +555,12 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
                       int act, int out_f32, int accumulate, hipStream_t stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
   if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
-  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return LMOD_EINVAL;
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return LMOD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return LMOD_EINVAL;
-  if (act < 0 || act > 2) return LMOD_EINVAL;
+  if (act < 0 || act > 3) return LMOD_EINVAL;
+  if (act == 3) {          // fused SwiGLU: bf16 C of N/2 columns, vector stores only
+    if (out_f32 || accumulate || (N & 15) || ldc < N / 2 || (ldc & 7) || ((uintptr_t)C & 15) || (strideC & 7)) return LMOD_EINVAL;
+  } else if (ldc < N) return LMOD_EINVAL;
   if ((long long)127 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   if ((long long)127 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   GemmP p;

@@ -31,7 +31,8 @@ def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False
             batch = a.shape[0]
             strides = (a.stride(0), b.stride(0) if b.dim() == 3 else 0, None)
     if out is None:
-        shape = (batch, M, N) if (a.dim() == 3) else (M, N)
+        Nc = N // 2 if act == 3 else N            # act 3: fused SwiGLU over interleaved (gate, up) weight rows
+        shape = (batch, M, Nc) if (a.dim() == 3) else (M, Nc)
         out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else BF16)
     if ldc is None:
         ldc = out.stride(-2)

@@ -27,8 +27,8 @@ class FusedWeight:
         self.groups = [list(g) for g in groups]
         self.bias_groups = [list(g) for g in bias_groups] if bias_groups is not None else None
         self.stacked = len(self.groups) > 1
-        self.w = self.b = self.wt = None
-        self._wt_version = None
+        self.w = self.b = self.wt = self.w_il = None
+        self._wt_version = self._il_version = None
         self.main_grad = None
         self.bias_main_grad = None
         self.pending = 0                 # wgrad contributions still to come in the current backward
@@ -99,6 +99,16 @@ class FusedWeight:
             self.wt = K.transpose(self.w, out=self.wt)
             self._wt_version = ver
         return self.wt
+
+    def interleaved(self):
+        """[2I, K] gate-over-up weight re-ordered in row blocks of 8 (g0..7, u0..7, g8..15, ...) for the GEMM's fused
+        SwiGLU epilogue (act=3).  Cached like the transpose; only built for weights used without a backward."""
+        ver = tuple(p._version for p in self.params)
+        if self.w_il is None or self._il_version != ver:
+            two_i, k = self.w.shape
+            self.w_il = self.w.view(2, two_i // 16, 8, k).transpose(0, 1).reshape(two_i, k).contiguous()
+            self._il_version = ver
+        return self.w_il
 
     def grad_buffer(self):
         if self.main_grad is None:
@@ -226,8 +236,11 @@ class MLPBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, spec, *params):
-        gu = linear_fwd(x, spec.gu)
         I = spec.gu.w.shape[0] // 2
+        if not any(ctx.needs_input_grad) and I % 8 == 0 and spec.gu.b is None:
+            # no backward (teacher / eval): SwiGLU runs in the gate/up GEMM's epilogue, [T, 2I] never exists
+            return linear_fwd(K.gemm_nt(x, spec.gu.interleaved(), act=3), spec.down)
+        gu = linear_fwd(x, spec.gu)
         act = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         out = linear_fwd(act, spec.down)
         ctx.spec = spec

@@ -79,6 +79,21 @@ def test_gemm_bias_act_f32_accumulate():
     close(acc, a.float() @ b.float().t() + 2.0, "gemm f32 accumulate", rtol=1e-4, afrac=1e-5)
 
 
+@pytest.mark.parametrize("M,I,K_", [(200, 136, 320), (1024, 1024, 256)])      # 128-tile and 256-tile kernels
+def test_gemm_fused_swiglu_epilogue(M, I, K_):
+    # act=3: weight rows interleaved (gate, up) in blocks of 8 -> C = silu(gate) * up, bit-identical to GEMM + swiglu kernel
+    x, wg, wu = rnd(M, K_, seed=30), rnd(I, K_, seed=31), rnd(I, K_, seed=32)
+    w = torch.cat([wg, wu], 0)
+    gu = K.gemm_nt(x, w)
+    ref = K.swiglu_fwd(gu[:, :I], gu[:, I:])
+    w_il = w.view(2, I // 8, 8, K_).transpose(0, 1).reshape(2 * I, K_).contiguous()
+    out = K.gemm_nt(x, w_il, act=3)
+    assert out.shape == (M, I)
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    gf, uf = x.float() @ wg.float().t(), x.float() @ wu.float().t()
+    close(out, F.silu(gf.to(BF).float()).to(BF).float() * uf.to(BF).float(), "fused swiglu vs torch")
+
+
 def test_gemm_strided_output_and_subview():
     # write into a column slice of a wider buffer (QKV / gate-up fusion pattern)
     M, N, K_ = 130, 96, 128
