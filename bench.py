@@ -237,8 +237,8 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            # dominant kernel (71 % of GPU time in profiles/): gemm_nt_256 at its largest shape, timed live above
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_256 @ teacher gate+up [{B * 2048}x22016x4096]",
+            # dominant kernel (71 % of GPU time in profiles/): gemm_256_kernel<0> (NT GEMM) at its largest shape, timed live above
+            "roofline": {"bound": "mfma", "kernel": f"gemm_256_kernel<0> (bf16 NT GEMM, 256x256x64 tiles) @ [{B * 2048}x22016x4096]",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(gemm_ms, 4),
                          "whole_step": {"achieved": round(achieved, 1), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

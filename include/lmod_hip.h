@@ -29,12 +29,20 @@ extern "C" {
  * :1163 (lm_head); multimodal_projector/builder.py:57-61; HF CLIP linears + patch conv
  * (multimodal_encoder/clip_encoder.py:54).  With m_valid/k_valid (device int[batch]) it is the
  * grouped GEMM over DeepSpeed MoE capacity slabs (deepspeed.moe.experts; llava_qwen2_moe.py:536-546).
- * act: 0 none, 1 exact GELU, 2 quick_gelu, 3 fused SwiGLU (B rows interleaved gate/up in blocks of 8;
- *      C is bf16 with N/2 columns = silu(gate) * up, N % 16 == 0).  out_f32: C is fp32.  accumulate: C += .
+ * act: 0 none, 1 exact GELU, 2 quick_gelu.  out_f32: C is fp32.  accumulate: C += .
  * Requires K % 8 == 0, lda/ldb % 8 == 0, A/B 16-byte aligned. */
 int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
                       int ldc, int batch, long long strideA, long long strideB, long long strideC, const int* m_valid,
                       const int* k_valid, int act, int out_f32, int accumulate, hipStream_t stream);
+
+/* Fused SwiGLU MLP input half: act_out[b] (M x N) = silu(A Wg^T) * (A Wu^T), W = [Wg; Wu] stored as ONE [2N x K]
+ * matrix (gate rows first — the fused gate_proj/up_proj weight; qwen2/modeling_qwen2.py:175-187, MoE experts
+ * llava_qwen2_moe.py:536-546).  gu_out (may be NULL): [M x 2N] bf16 pre-activations [gate | up] kept for backward.
+ * m_valid as in lmod_gemm_bf16_nt; rows m_valid..roundup8(m_valid)-1 of act_out are written as zeros.
+ * Requires K % 8 == 0, N % 8 == 0, 16-byte aligned pointers, leading dims % 8 == 0. */
+int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_out, int M, int N, int K, int lda,
+                          int ldw, int ld_act, int ld_gu, int batch, long long strideA, long long strideW,
+                          long long stride_act, long long stride_gu, const int* m_valid, hipStream_t stream);
 
 /* out[C x ld_out] = in[R x C]^T, zero-filling columns R..ld_out-1 (makes dgrad / wgrad operands
  * K-contiguous for lmod_gemm_bf16_nt; autograd's implicit .t() in the reference). */

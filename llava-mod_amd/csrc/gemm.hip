@@ -26,19 +26,18 @@ struct GemmP {
   int M, N, K, lda, ldb, ldc;
   int batch; long long sA, sB, sC;
   const int* m_valid; const int* k_valid;
-  int act;         // 0 none, 1 exact GELU, 2 quick_gelu, 3 SwiGLU over (gate, up) column blocks of 8 -> C has N/2 columns
+  int act;         // 0 none, 1 exact GELU, 2 quick_gelu
   int out_f32;     // 0: bf16 C, 1: f32 C
   int accumulate;  // C += result (read-modify-write)
   int vec_ok;      // C pointer / ldc allow 16-byte vector stores
   int tiles_m, tiles_n;
+  void* C2; int ldc2; long long sC2;   // gemm_swiglu_256 only: optional [M, 2N] gate|up pre-activations
 };
 
 #define GEMM_OOB 0x80000000u
 
-// act 3: the weight rows are interleaved in blocks of 8 (g0..7, u0..7, g8..15, u8..15, ...), so the 16 contiguous
-// output columns a lane owns are 8 gate values and their 8 up values: silu(gate) * up leaves as ONE 16-byte store
-// of the half-width activation (same roundings as the separate kernel: bf16 gate/up, bf16 silu, bf16 product;
-// reference qwen2/modeling_qwen2.py:186-187).
+// Fused SwiGLU epilogue (gemm_swiglu_256): v[0..7] are 8 gate pre-activations, v[8..15] the matching 8 up values.
+// Same roundings as GEMM + the separate kernel: bf16 gate/up, bf16 silu, bf16 product (qwen2/modeling_qwen2.py:186-187).
 __device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
   u32x4 o;
 #pragma unroll
@@ -218,10 +217,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
-    if (p.act == 3) {          // N % 16 == 0 and 16-byte aligned C are checked on the host
-      if (cb < p.N) *(u32x4*)((bf16_t*)Cb + (long long)row * p.ldc + (cb >> 1)) = swiglu_pairs(v);
-      continue;
-    }
     if (p.act) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
@@ -288,7 +283,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 #define G256_STAGGER 1
 #endif
 
-__global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
+// MODE 0: plain NT GEMM.  MODE 1 (gemm_swiglu_256): B is the [2N, K] gate-over-up weight; an N tile is 128 output
+// columns fed by 128 gate rows (B half-tile nh0) and the matching 128 up rows (nh1), staged so that every lane
+// ends up with 8 contiguous gate columns and the same 8 up columns -> C = silu(gate) * up leaves as one 16-byte
+// store and the [M, 2N] pre-activations are written only if the backward needs them (C2).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
+  constexpr int TN = MODE ? 128 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
   int tm = first_m + rr % gsz, tn = rr / gsz;
   if (p.m_valid) {   // grouped launch: see gemm_nt_128
     if (p.batch <= GEMM_MAX_GROUPS) {
-      if (!grouped_tile<256, G256_GROUP_M>(p, bz, tm, tn)) return;
+      if (!grouped_tile<256, G256_GROUP_M>(p, bz, tm, tn)) return;    // (row tiles are 256 in both modes)
     } else {
       const int per_col = p.batch * p.tiles_m;
       tn = id / per_col;
@@ -317,15 +318,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
   }
   int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
   int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
-  const int row0 = tm * 256, col0 = tn * 256;
+  const int row0 = tm * 256, col0 = tn * TN;
   if (row0 >= Mv) return;
 
   const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda;
   const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb;
-  const int rowsA = min(256, Mv - row0), rowsB = min(256, p.N - col0);
+  const int rowsA = min(256, Mv - row0), rowsB = min(TN, p.N - col0);
   const int Kv8 = (Kv + 7) & ~7;
   const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
-  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)(rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
+  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
 
@@ -340,8 +341,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
       const int ra = (hr >> 6) * 128 + h * 64 + (hr & 63);             // A: tile row
       voA[h][j] = (ra < rowsA) ? (uint32_t)((ra * p.lda + cchunk * 8) * 2) : GEMM_OOB;
       const int wcs = hr >> 5, rl = hr & 31, ntl = rl >> 4, ii = rl & 15;
-      const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
-      voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+      if (MODE == 0) {
+        const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
+        voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+      } else {       // half h = gate (0) / up (1) rows of the same 128 output columns
+        const int nloc = wcs * 32 + (ii >> 2) * 8 + ntl * 4 + (ii & 3);
+        voB[h][j] = (nloc < rowsB) ? (uint32_t)((((long long)h * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+      }
     }
 
   f32x4 acc[8][4];
@@ -445,6 +451,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
 
   // ---- epilogue: lane holds, for each mt, row (lane&15) and 16 contiguous columns ----
   const int g = lane >> 4;
+  if constexpr (MODE == 1) {      // 8 gate + 8 up columns per lane
+    const int cs = col0 + wc * 32 + g * 8;
+    bf16_t* Cact = (bf16_t*)p.C + (long long)bz * p.sC;
+    bf16_t* Cgu = p.C2 ? (bf16_t*)p.C2 + (long long)bz * p.sC2 : nullptr;
+    const int Mz = min((Mv + 7) & ~7, p.M);      // rows Mv..Mz-1 are zero-filled: a k_valid wgrad reads whole 8-row chunks
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = row0 + wr * 128 + mt * 16 + li;
+      if (row >= Mz || cs >= p.N) continue;
+      if (row >= Mv) { *(u32x4*)(Cact + (long long)row * p.ldc + cs) = (u32x4){0u, 0u, 0u, 0u}; continue; }
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q];
+      *(u32x4*)(Cact + (long long)row * p.ldc + cs) = swiglu_pairs(v);
+      if (Cgu) {
+        const u32x4 o0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        const u32x4 o1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+        *(u32x4*)(Cgu + (long long)row * p.ldc2 + cs) = o0;
+        *(u32x4*)(Cgu + (long long)row * p.ldc2 + p.N + cs) = o1;
+      }
+    }
+    return;
+  }
   const int cb = col0 + wc * 64 + g * 16;
   float bia[16];
 #pragma unroll
@@ -467,10 +498,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(GemmP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
-    if (p.act == 3) {
-      if (cb < p.N) *(u32x4*)((bf16_t*)Cb + (long long)row * p.ldc + (cb >> 1)) = swiglu_pairs(v);
-      continue;
-    }
     if (p.act) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
@@ -557,10 +584,7 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
   if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return LMOD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return LMOD_EINVAL;
-  if (act < 0 || act > 3) return LMOD_EINVAL;
-  if (act == 3) {          // fused SwiGLU: bf16 C of N/2 columns, vector stores only
-    if (out_f32 || accumulate || (N & 15) || ldc < N / 2 || (ldc & 7) || ((uintptr_t)C & 15) || (strideC & 7)) return LMOD_EINVAL;
-  } else if (ldc < N) return LMOD_EINVAL;
+  if (act < 0 || act > 2 || ldc < N) return LMOD_EINVAL;
   if ((long long)127 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   if ((long long)127 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   GemmP p;
@@ -569,6 +593,7 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.m_valid = m_valid; p.k_valid = k_valid;
   p.act = act; p.out_f32 = out_f32; p.accumulate = accumulate;
+  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0;
   const int esz = out_f32 ? 4 : 2;
   p.vec_ok = (((uintptr_t)C & 15) == 0) && ((((long long)ldc * esz) & 15) == 0) &&
              (((strideC * esz) & 15) == 0);
@@ -576,7 +601,7 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_128, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_256, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
     const char* e = getenv("LMOD_GEMM_TILE");
     force_tile = e ? atoi(e) : 0;
     attr_set = true;
@@ -595,8 +620,40 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   p.tiles_m = (M + T - 1) / T; p.tiles_n = (N + T - 1) / T;
   const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
-  if (big) hipLaunchKernelGGL(gemm_nt_256, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  if (big) hipLaunchKernelGGL(gemm_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   else hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  return lmod_launch_status();
+}
+
+// act_out[b] (M x N) = silu(A Wg^T) * (A Wu^T) with W = [Wg; Wu] the [2N, K] gate-over-up weight (row stride ldw);
+// gu_out (optional, M x 2N, ld_gu) receives the bf16 pre-activations [gate | up] for the backward.
+// Grouped use as lmod_gemm_bf16_nt (m_valid: live rows per batch; rows up to the next multiple of 8 are zeroed in act_out).
+int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_out, int M, int N, int K, int lda,
+                          int ldw, int ld_act, int ld_gu, int batch, long long strideA, long long strideW,
+                          long long stride_act, long long stride_gu, const int* m_valid, hipStream_t stream) {
+  if (!A || !W || !act_out || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if ((K & 7) || (N & 7) || (lda & 7) || (ldw & 7) || lda < K || ldw < K || ld_act < N || (ld_act & 7)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)act_out & 15) || (stride_act & 7)) return LMOD_EINVAL;
+  if (gu_out && (ld_gu < 2 * N || (ld_gu & 7) || ((uintptr_t)gu_out & 15) || (stride_gu & 7))) return LMOD_EINVAL;
+  if ((long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  if (((long long)N + 127) * ldw * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = act_out; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ld_act;
+  p.batch = batch; p.sA = strideA; p.sB = strideW; p.sC = stride_act;
+  p.m_valid = m_valid; p.k_valid = nullptr;
+  p.act = 0; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
+  p.C2 = gu_out; p.ldc2 = ld_gu; p.sC2 = stride_gu;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    attr_set = true;
+  }
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 127) / 128;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  hipLaunchKernelGGL(gemm_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   return lmod_launch_status();
 }
 

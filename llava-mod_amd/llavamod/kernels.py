@@ -31,8 +31,7 @@ def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False
             batch = a.shape[0]
             strides = (a.stride(0), b.stride(0) if b.dim() == 3 else 0, None)
     if out is None:
-        Nc = N // 2 if act == 3 else N            # act 3: fused SwiGLU over interleaved (gate, up) weight rows
-        shape = (batch, M, Nc) if (a.dim() == 3) else (M, Nc)
+        shape = (batch, M, N) if (a.dim() == 3) else (M, N)
         out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else BF16)
     if ldc is None:
         ldc = out.stride(-2)
@@ -42,6 +41,26 @@ def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False
     call("lmod_gemm_bf16_nt", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, lda, ldb, ldc, batch, sA, sB, sC,
          ptr(m_valid), ptr(k_valid), act, int(out_f32), int(accumulate))
     return out
+
+
+def gemm_swiglu(x, w_gu, act=None, gu=None, want_gu=False, m_valid=None):
+    """act[.., M, I] = silu(x @ Wg^T) * (x @ Wu^T) for the fused gate-over-up weight w_gu [.., 2I, K] in ONE GEMM launch
+    (SwiGLU in the epilogue).  x: [M, K] or [E, M, K] (grouped, weights [E, 2I, K] or shared [2I, K]).
+    gu (or want_gu): also store the [.., M, 2I] pre-activations for the backward.  Returns (act, gu-or-None)."""
+    M, Kd = x.shape[-2], x.shape[-1]
+    I = w_gu.shape[-2] // 2
+    batch = x.shape[0] if x.dim() == 3 else 1
+    lead = (batch,) if x.dim() == 3 else ()
+    if act is None:
+        act = torch.empty(lead + (M, I), device=x.device, dtype=BF16)
+    if gu is None and want_gu:
+        gu = torch.empty(lead + (M, 2 * I), device=x.device, dtype=BF16)
+    call("lmod_gemm_swiglu_bf16", ptr(x), ptr(w_gu), ptr(act), ptr(gu), M, I, Kd, x.stride(-2), w_gu.stride(-2),
+         act.stride(-2), gu.stride(-2) if gu is not None else 0, batch,
+         x.stride(0) if x.dim() == 3 else 0, w_gu.stride(0) if w_gu.dim() == 3 else 0,
+         act.stride(0) if act.dim() == 3 else 0, (gu.stride(0) if gu.dim() == 3 else 0) if gu is not None else 0,
+         ptr(m_valid))
+    return act, gu
 
 
 def transpose(x, ld_out=None, out=None):

@@ -27,8 +27,8 @@ class FusedWeight:
         self.groups = [list(g) for g in groups]
         self.bias_groups = [list(g) for g in bias_groups] if bias_groups is not None else None
         self.stacked = len(self.groups) > 1
-        self.w = self.b = self.wt = self.w_il = None
-        self._wt_version = self._il_version = None
+        self.w = self.b = self.wt = None
+        self._wt_version = None
         self.main_grad = None
         self.bias_main_grad = None
         self.pending = 0                 # wgrad contributions still to come in the current backward
@@ -99,16 +99,6 @@ class FusedWeight:
             self.wt = K.transpose(self.w, out=self.wt)
             self._wt_version = ver
         return self.wt
-
-    def interleaved(self):
-        """[2I, K] gate-over-up weight re-ordered in row blocks of 8 (g0..7, u0..7, g8..15, ...) for the GEMM's fused
-        SwiGLU epilogue (act=3).  Cached like the transpose; only built for weights used without a backward."""
-        ver = tuple(p._version for p in self.params)
-        if self.w_il is None or self._il_version != ver:
-            two_i, k = self.w.shape
-            self.w_il = self.w.view(2, two_i // 16, 8, k).transpose(0, 1).reshape(two_i, k).contiguous()
-            self._il_version = ver
-        return self.w_il
 
     def grad_buffer(self):
         if self.main_grad is None:
@@ -232,20 +222,22 @@ class AttnBlock(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ dense SwiGLU MLP
 class MLPBlock(torch.autograd.Function):
-    """down(silu(gate(x)) * up(x)) with gate/up as ONE [2I, H] GEMM (qwen2/modeling_qwen2.py:175-187)."""
+    """down(silu(gate(x)) * up(x)) (qwen2/modeling_qwen2.py:175-187): gate/up is ONE GEMM against the fused [2I, H]
+    weight with SwiGLU in its epilogue; the [T, 2I] pre-activations are only written when a backward will read them."""
 
     @staticmethod
     def forward(ctx, x, spec, *params):
-        I = spec.gu.w.shape[0] // 2
-        if not any(ctx.needs_input_grad) and I % 8 == 0 and spec.gu.b is None:
-            # no backward (teacher / eval): SwiGLU runs in the gate/up GEMM's epilogue, [T, 2I] never exists
-            return linear_fwd(K.gemm_nt(x, spec.gu.interleaved(), act=3), spec.down)
-        gu = linear_fwd(x, spec.gu)
-        act = K.swiglu_fwd(gu[:, :I], gu[:, I:])
+        need = any(ctx.needs_input_grad)
+        if spec.gu.b is None:
+            act, gu = K.gemm_swiglu(x, spec.gu.w, want_gu=need)
+        else:
+            gu = linear_fwd(x, spec.gu)
+            I = spec.gu.w.shape[0] // 2
+            act = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         out = linear_fwd(act, spec.down)
         ctx.spec = spec
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, gu)
+        if need:
+            ctx.save_for_backward(x, gu, act if spec.down.requires_grad else None)
             for fw in (spec.gu, spec.down):
                 if fw.requires_grad:
                     fw.note_use()
@@ -254,14 +246,12 @@ class MLPBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         sp = ctx.spec
-        x, gu = ctx.saved_tensors
+        x, gu, act = ctx.saved_tensors
         I = sp.gu.w.shape[0] // 2
         dout = dout.contiguous()
         dact = linear_dgrad(dout, sp.down)
         if sp.down.requires_grad:
-            act = K.swiglu_fwd(gu[:, :I], gu[:, I:])          # recomputed, not stored
             linear_wgrad(dout, act, sp.down)
-            del act
         dgu = torch.empty_like(gu)
         K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         dx = linear_dgrad(dgu, sp.gu)
@@ -351,17 +341,16 @@ class MoEBlock(torch.autograd.Function):
         rows = st.slots_used
         disp = K.gather_rows(x, None, st.slot_token, H)                       # [E*C, H], zero rows on empty slots
         I = spec.gu.w.shape[1] // 2
-        gu = torch.empty((E, C, 2 * I), device=x.device, dtype=BF16)
-        K.gemm_nt(disp.view(E, C, H), spec.gu.w, out=gu, m_valid=rows)
-        gu2 = gu.view(E * C, 2 * I)
-        act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rows)
+        need = any(ctx.needs_input_grad)
+        # grouped gate/up GEMM with SwiGLU in the epilogue (dead rows up to the next multiple of 8 are zeroed in act)
+        act, gu = K.gemm_swiglu(disp.view(E, C, H), spec.gu.w, want_gu=need, m_valid=rows)
         y = torch.empty((E, C, H), device=x.device, dtype=BF16)
-        K.gemm_nt(act.view(E, C, I), spec.down.w, out=y, m_valid=rows)
+        K.gemm_nt(act, spec.down.w, out=y, m_valid=rows)
         out = K.moe_combine_fwd(y.view(E * C, H), st, H)
         ctx.spec, ctx.st = spec, st
         spec.last_state = st
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, disp, gu, y)
+        if need:
+            ctx.save_for_backward(x, disp, gu, y, act if spec.down.requires_grad else None)
             for fw in (spec.gu, spec.down):
                 if fw.requires_grad:
                     fw.note_use()
@@ -372,7 +361,7 @@ class MoEBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dlaux, _dc):
         sp, st = ctx.spec, ctx.st
-        x, disp, gu, y = ctx.saved_tensors
+        x, disp, gu, y, act = ctx.saved_tensors
         T, H = x.shape
         E, C = st.E, st.C
         I = sp.gu.w.shape[1] // 2
@@ -384,11 +373,9 @@ class MoEBlock(torch.autograd.Function):
         K.gemm_nt(dy.view(E, C, H), sp.down.transposed(), out=dact, m_valid=rows)
         gu2 = gu.view(E * C, 2 * I)
         if sp.down.requires_grad:
-            act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rows)
-            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act.view(E, C, I)), out=sp.down.grad_buffer(),
+            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act), out=sp.down.grad_buffer(),
                       out_f32=True, accumulate=True, k_valid=rows)
             sp.down.grad_done()
-            del act
         dgu = torch.empty_like(gu)
         dgu2 = dgu.view(E * C, 2 * I)
         K.swiglu_bwd(dact.view(E * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rows)
@@ -569,17 +556,14 @@ class ExpertFFN(torch.autograd.Function):
     def forward(ctx, x, spec, rows, *params):
         ep, El, C, H = x.shape
         I = spec.gu.w.shape[-2] // 2
-        gu = torch.empty((ep, El, C, 2 * I), device=x.device, dtype=BF16)
-        act = torch.empty((ep, El, C, I), device=x.device, dtype=BF16)
-        y = torch.empty_like(x)
+        need = any(ctx.needs_input_grad)
+        gu = torch.empty((ep, El, C, 2 * I), device=x.device, dtype=BF16) if need else None
+        act = torch.zeros((ep, El, C, I), device=x.device, dtype=BF16)    # dead rows stay zero (wgrad reads whole slabs)
         for le in range(El):          # one grouped launch per local expert: batch = source ranks, shared weights
             mv = rows[:, le].contiguous() if rows is not None else None
             wgu = spec.gu.w[le] if spec.gu.stacked else spec.gu.w
-            K.gemm_nt(x[:, le], wgu, out=gu[:, le], M=C, N=2 * I, K=H, lda=H, ldb=H, ldc=2 * I, batch=ep,
-                      strides=(El * C * H, 0, El * C * 2 * I), m_valid=mv)
-        gu2 = gu.view(ep * El * C, 2 * I)
-        rflat = rows.reshape(-1).contiguous() if rows is not None else None
-        K.swiglu_fwd(gu2[:, :I], gu2[:, I:], out=act.view(ep * El * C, I), seg_rows=C, seg_valid=rflat)
+            K.gemm_swiglu(x[:, le], wgu, act=act[:, le], gu=gu[:, le] if need else None, m_valid=mv)
+        y = torch.empty_like(x)
         for le in range(El):
             mv = rows[:, le].contiguous() if rows is not None else None
             wd = spec.down.w[le] if spec.down.stacked else spec.down.w
@@ -587,8 +571,8 @@ class ExpertFFN(torch.autograd.Function):
                       strides=(El * C * I, 0, El * C * H), m_valid=mv)
         # rows past a slab's live count are not computed: the receiving combine never reads them (empty slots)
         ctx.spec, ctx.shape, ctx.I = spec, (ep, El, C, H), I
-        ctx.save_for_backward(x, gu, rows)
-        if any(ctx.needs_input_grad):
+        ctx.save_for_backward(x, gu, rows, act if (need and spec.down.requires_grad) else None)
+        if need:
             for fw in (spec.gu, spec.down):
                 if fw.requires_grad:
                     fw.note_use()
@@ -597,7 +581,7 @@ class ExpertFFN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         sp = ctx.spec
-        x, gu, rows = ctx.saved_tensors
+        x, gu, rows, act = ctx.saved_tensors
         ep, El, C, H = ctx.shape
         I = ctx.I
         dy = dy.contiguous()
@@ -611,7 +595,6 @@ class ExpertFFN(torch.autograd.Function):
         gu2 = gu.view(ep * El * C, 2 * I)
         rflat = rows.reshape(-1).contiguous() if rows is not None else None
         if sp.down.requires_grad:
-            act = K.swiglu_fwd(gu2[:, :I], gu2[:, I:], seg_rows=C, seg_valid=rflat).view(ep, El, C, I)
             g = sp.down.grad_buffer()
             if El == 1:     # slabs of all source ranks are contiguous: ONE wgrad GEMM over K = ep*C (dead rows are zero)
                 K.gemm_nt(K.transpose(dy.view(ep * C, H)), K.transpose(act.view(ep * C, I)),
@@ -623,7 +606,6 @@ class ExpertFFN(torch.autograd.Function):
                         K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
                                   out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
             sp.down.grad_done()
-            del act
         dgu = torch.empty_like(gu)
         dgu2 = dgu.view(ep * El * C, 2 * I)
         K.swiglu_bwd(dact.view(ep * El * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rflat)

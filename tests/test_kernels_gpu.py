@@ -79,19 +79,35 @@ def test_gemm_bias_act_f32_accumulate():
     close(acc, a.float() @ b.float().t() + 2.0, "gemm f32 accumulate", rtol=1e-4, afrac=1e-5)
 
 
-@pytest.mark.parametrize("M,I,K_", [(200, 136, 320), (1024, 1024, 256)])      # 128-tile and 256-tile kernels
-def test_gemm_fused_swiglu_epilogue(M, I, K_):
-    # act=3: weight rows interleaved (gate, up) in blocks of 8 -> C = silu(gate) * up, bit-identical to GEMM + swiglu kernel
-    x, wg, wu = rnd(M, K_, seed=30), rnd(I, K_, seed=31), rnd(I, K_, seed=32)
-    w = torch.cat([wg, wu], 0)
-    gu = K.gemm_nt(x, w)
-    ref = K.swiglu_fwd(gu[:, :I], gu[:, I:])
-    w_il = w.view(2, I // 8, 8, K_).transpose(0, 1).reshape(2 * I, K_).contiguous()
-    out = K.gemm_nt(x, w_il, act=3)
-    assert out.shape == (M, I)
-    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
-    gf, uf = x.float() @ wg.float().t(), x.float() @ wu.float().t()
-    close(out, F.silu(gf.to(BF).float()).to(BF).float() * uf.to(BF).float(), "fused swiglu vs torch")
+@pytest.mark.parametrize("M,I,K_", [(200, 136, 320), (1024, 1152, 256), (300, 5504, 128)])
+def test_gemm_fused_swiglu(M, I, K_):
+    # ONE launch: silu(x Wg^T) * (x Wu^T) against the fused [2I, K] weight, bit-identical to GEMM + swiglu kernel
+    x, w = rnd(M, K_, seed=30), rnd(2 * I, K_, seed=31)
+    gu_ref = K.gemm_nt(x, w)
+    ref = K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:])
+    act, gu = K.gemm_swiglu(x, w, want_gu=True)
+    assert act.shape == (M, I) and gu.shape == (M, 2 * I)
+    assert torch.equal(gu, gu_ref), "pre-activations differ from the plain GEMM"
+    assert torch.equal(act, ref), float((act.float() - ref.float()).abs().max())
+    act2, none = K.gemm_swiglu(x, w)
+    assert none is None and torch.equal(act2, ref)
+    gf, uf = x.float() @ w[:I].float().t(), x.float() @ w[I:].float().t()
+    close(act, F.silu(gf.to(BF).float()).to(BF).float() * uf.to(BF).float(), "fused swiglu vs torch")
+
+
+def test_gemm_fused_swiglu_grouped():
+    E, C, H, I = 4, 200, 128, 264
+    x, w = rnd(E, C, H, seed=33), rnd(E, 2 * I, H, seed=34)
+    mv = torch.tensor([200, 0, 77, 130], device=DEV, dtype=torch.int32)
+    act = torch.full((E, C, I), 7.0, device=DEV, dtype=BF)
+    K.gemm_swiglu(x, w, act=act, m_valid=mv)
+    for e in range(E):
+        n = int(mv[e]); n8 = min((n + 7) // 8 * 8, C)
+        if n:
+            gu = K.gemm_nt(x[e, :n].contiguous(), w[e])
+            assert torch.equal(act[e, :n], K.swiglu_fwd(gu[:, :I], gu[:, I:])), f"expert {e}"
+        assert act[e, n:n8].abs().max().item() == 0 if n8 > n else True, "rows up to the next multiple of 8 must be zeroed"
+        assert n8 == C or (act[e, n8:] == 7.0).all(), "rows past the zeroed chunk must not be written"
 
 
 def test_gemm_strided_output_and_subview():
