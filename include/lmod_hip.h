@@ -44,6 +44,24 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
                           int ldw, int ld_act, int ld_gu, int batch, long long strideA, long long strideW,
                           long long stride_act, long long stride_gu, const int* m_valid, hipStream_t stream);
 
+/* Weight-gradient accumulate with deterministic split-K: C (fp32, M x N) += At (M x K) * Bt (N x K)^T for long K
+ * (tokens) and few output tiles (main_grad accumulation of nn.Linear weights; the reference gets this from autograd +
+ * DeepSpeed's fp32 gradient accumulation).  workspace: 16-byte aligned device memory, zeroed ONCE by the caller, used
+ * by one stream at a time: 16 KiB of tile semaphores (self-resetting) + up to 8 partial [M x N] fp32 images; its size
+ * bounds the split (NULL: plain lmod_gemm_bf16_nt with out_f32 + accumulate).  The last split to arrive adds all
+ * partials in split order, so the result does not depend on scheduling. */
+int lmod_gemm_wgrad_bf16_nt(const void* At, const void* Bt, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            void* workspace, long long workspace_bytes, hipStream_t stream);
+
+/* Weight-gradient GEMM: C[b] (M x N) (+)= A[b]^T * B[b], A [K x M] (lda), B [K x N] (ldb) — dW = dY^T X on the
+ * token-major tensors autograd holds (the implicit grad_output.t() @ input of nn.Linear's backward; reference
+ * linears as in lmod_gemm_bf16_nt).  k_valid (device int[batch]): live reduction rows per batch (MoE capacity slots).
+ * Split-K: batch = S, strideA = Kc*lda, strideB = Kc*ldb, C = [S, M, N] workspace.
+ * Requires M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned pointers. */
+int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                      long long strideA, long long strideB, long long strideC, const int* k_valid, int out_f32,
+                      int accumulate, hipStream_t stream);
+
 /* out[C x ld_out] = in[R x C]^T, zero-filling columns R..ld_out-1 (makes dgrad / wgrad operands
  * K-contiguous for lmod_gemm_bf16_nt; autograd's implicit .t() in the reference). */
 int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int ld_out, int batch,

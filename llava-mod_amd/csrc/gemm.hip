@@ -32,6 +32,8 @@ struct GemmP {
   int vec_ok;      // C pointer / ldc allow 16-byte vector stores
   int tiles_m, tiles_n;
   void* C2; int ldc2; long long sC2;   // gemm_swiglu_256 only: optional [M, 2N] gate|up pre-activations
+  int splitk, kchunk;                  // MODE 0, batch 1, fp32 accumulate: deterministic split-K (lmod_gemm_wgrad_bf16_nt)
+  float* ws; int* counters;            //   ws [splitk, M, N] partial tiles, counters [tiles] arrival semaphores (self-resetting)
 };
 
 #define GEMM_OOB 0x80000000u
@@ -287,17 +289,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 // columns fed by 128 gate rows (B half-tile nh0) and the matching 128 up rows (nh1), staged so that every lane
 // ends up with 8 contiguous gate columns and the same 8 up columns -> C = silu(gate) * up leaves as one 16-byte
 // store and the [M, 2N] pre-activations are written only if the backward needs them (C2).
+// MODE 2 (wgrad, "TN"): C[M,N] (+)= A^T B with BOTH operands reduction-major as autograd hands them over
+// (A = dY [K, M], B = X [K, N], K = tokens): no transposed copies.  A half-tile is a [64 k][128 m] image (256-byte
+// rows, 32-byte blocks XOR-swizzled by (k&3 | (k>>3&1)<<2)) filled by LDS-DMA; the MFMA operand fragments (8
+// consecutive k for one m per lane) come out of it through ds_read_b64_tr_b16 (hardware transpose read),
+// conflict-free.  Columns are in natural order, so a lane owns 4 groups of 4 contiguous output columns.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
-  constexpr int TN = MODE ? 128 : 256;
+  constexpr int TN = (MODE == 1) ? 128 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tpb = p.tiles_m * p.tiles_n;
-  int bz = id / tpb;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  int bz = id / tpb, split = 0;
+  if (MODE == 0 && p.splitk > 1) {      // split-major: an XCD's contiguous chunk is many tiles of ONE K split (same L2 reuse)
+    split = bz; bz = 0; id -= split * tpb;
+  }
   const int r = id - bz * tpb;
   const int GROUP_M = G256_GROUP_M;
   const int grp = r / (GROUP_M * p.tiles_n);
@@ -320,19 +330,39 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
   const int row0 = tm * 256, col0 = tn * TN;
   if (row0 >= Mv) return;
+  int kbeg = 0;
+  if (MODE == 0 && p.splitk > 1) {      // long-K, few-tile problems (wgrad): the batch index is the K split
+    kbeg = split * p.kchunk;
+    Kv = max(0, min(Kv - kbeg, p.kchunk));      // an empty split still arrives at the semaphore with a zero tile
+  }
 
-  const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda;
-  const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb;
+  const bf16_t* Ab = p.A + (long long)bz * p.sA + (MODE == 2 ? (long long)row0 : (long long)row0 * p.lda) + kbeg;
+  const bf16_t* Bb = p.B + (long long)bz * p.sB + (MODE == 2 ? (long long)col0 : (long long)col0 * p.ldb) + kbeg;
   const int rowsA = min(256, Mv - row0), rowsB = min(TN, p.N - col0);
   const int Kv8 = (Kv + 7) & ~7;
   const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
-  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
+  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE == 1 ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
 
   // ---- staging offsets: this wave fills half-tile rows 16*wave + 8*j + (lane>>3), physical chunk lane&7 ----
   const int cchunk = (lane & 7) ^ (lane >> 3);
   uint32_t voA[2][2], voB[2][2];      // [half][j]
+  if constexpr (MODE == 2) {
+    // reduction-major image: this wave fills k rows 8*wave + 4*j + (lane>>4), physical 16-byte chunk lane&15
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int krow = wave * 8 + j * 4 + (lane >> 4), pc = lane & 15;
+        const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
+        const int mp = ((((pc >> 1) ^ key) << 1) | (pc & 1)) * 8;      // logical position 0..127 in the half-tile
+        const int ra = (mp >> 6) * 128 + h * 64 + (mp & 63);           // A: tile row (both wave rows' M-half h)
+        const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
+        voA[h][j] = (ra < rowsA) ? (uint32_t)((krow * p.lda + ra) * 2) : GEMM_OOB;
+        voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
+      }
+  } else {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -349,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((((long long)h * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       }
     }
+  }
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -362,6 +393,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   auto stage = [&](int kind, int t) {
     const int k0 = t * 64;
     char* dst = smem + (t & 1) * (4 * G256_SLOT) + kind * G256_SLOT + wave * 2048;
+    if constexpr (MODE == 2) {
+      // the K advance goes into the (64-bit) base: byte offsets of a token-major operand overflow 32 bits
+      const long long adv = (long long)k0 * (kind < 2 ? p.lda : p.ldb);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((kind < 2 ? Ab : Bb) + adv), 0,
+                                                                    (int)0x80000000u, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
+        if (k0 + wave * 8 + j * 4 + (lane >> 4) >= Kv) v = GEMM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + j * 1024), 16, v, 0, 0, 0);
+      }
+    } else {
     const bool dead = (k0 + cchunk * 8 >= Kv);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -369,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       if (dead) v = GEMM_OOB;
       if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+    }
     }
   };
 
@@ -378,7 +422,27 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const int ph1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
 
   bf16x8 af[4][2], bfr[2][2];
+  // MODE 2: per-lane pieces of the transposing read (see the kernel header): k row g*8 + (i>>2) (+4 for the second
+  // half of the fragment, +32 per k-step), 8 bytes at (i&3)*8 inside the 32-byte block (m-tile index ^ key)
+  const int trk = ((lane >> 4) * 8 + (li >> 2)) * 256 + (li & 3) * 8;
+  const int trkey = ((li >> 2) & 3) | (((lane >> 4) & 1) << 2);
+  auto read_tr16 = [&](const char* slot, int blk, int kk) -> bf16x8 {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const char* q = slot + kk * 8192 + trk + ((blk ^ trkey) << 5);
+    const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
+    const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 1024));
+    return (bf16x8){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  };
   auto readA = [&](int t, int mh) {
+    if constexpr (MODE == 2) {
+      const char* sl = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT;
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml) {
+        af[ml][0] = read_tr16(sl, wr * 4 + ml, 0);
+        af[ml][1] = read_tr16(sl, wr * 4 + ml, 1);
+      }
+      return;
+    }
     const char* s = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT + wr * 8192 + rdrow;
 #pragma unroll
     for (int ml = 0; ml < 4; ++ml) {
@@ -387,6 +451,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     }
   };
   auto readB = [&](int t, int nh) {
+    if constexpr (MODE == 2) {
+      const char* sl = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT;
+#pragma unroll
+      for (int nl = 0; nl < 2; ++nl) {
+        bfr[nl][0] = read_tr16(sl, wc * 2 + nl, 0);
+        bfr[nl][1] = read_tr16(sl, wc * 2 + nl, 1);
+      }
+      return;
+    }
     const char* s = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT + wc * 4096 + rdrow;
 #pragma unroll
     for (int nl = 0; nl < 2; ++nl) {
@@ -476,6 +549,34 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     }
     return;
   }
+  if constexpr (MODE == 2) {      // natural column order: lane owns columns cw + nt*16 + g*4 + (0..3), nt = 0..3
+    const int cw = col0 + wc * 64 + g * 4;
+    char* Cb2 = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : 2);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = row0 + wr * 128 + mt * 16 + li;
+      if (row >= Mv) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = cw + nt * 16;
+        if (col >= p.N) continue;            // N % 4 == 0 (host-checked): groups of 4 are all in or all out
+        f32x4 o = acc[mt][nt];
+        if (p.out_f32) {
+          float* cp = (float*)Cb2 + (long long)row * p.ldc + col;
+          if (p.accumulate) o += *(f32x4*)cp;
+          *(f32x4*)cp = o;
+        } else {
+          bf16_t* cp = (bf16_t*)Cb2 + (long long)row * p.ldc + col;
+          if (p.accumulate) {
+            const u32x2 old = *(u32x2*)cp;
+            o += (f32x4){bflo(old[0]), bfhi(old[0]), bflo(old[1]), bfhi(old[1])};
+          }
+          *(u32x2*)cp = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+      }
+    }
+    return;
+  }
   const int cb = col0 + wc * 64 + g * 16;
   float bia[16];
 #pragma unroll
@@ -504,7 +605,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     }
     if (p.out_f32) {
       float* cp = (float*)Cb + (long long)row * p.ldc + cb;
-      if (full) {
+      if (p.splitk > 1) {        // partial tile -> workspace (lane-linear, 1 KiB per store); the last split reduces (below)
+        float* wp = p.ws + (((long long)split * tpb + id) * 32 + mt * 4) * 2048 + tid * 4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const f32x4 o = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + x * 2048), "v"(o) : "memory");
+        }
+      } else if (full) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           f32x4 o = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
@@ -528,6 +636,53 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
           if (cb + x < p.N) cp[x] = f2bf(p.accumulate ? bf2f(cp[x]) + v[x] : v[x]);
       }
     }
+  }
+  if (MODE == 0 && p.splitk > 1) {
+    // Deterministic split-K reduction: every split publishes its partial tile, the LAST one to arrive adds all of
+    // them in split order (its own included, re-read) plus the old C.  Arrival order never changes the result.
+    // The splits of a tile run on different XCDs (private L2s): the partials move with agent-scope (sc1) stores and
+    // loads, ordered by vmcnt(0) + the semaphore atomic — no cache-wide writeback / invalidate fences.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = (int*)smem;                         // the LDS tiles are dead by now
+    if (tid == 0)
+      *flag = (__hip_atomic_fetch_add(p.counters + id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.splitk - 1);
+    __syncthreads();
+    if (!*flag) return;
+    float* Cf = (float*)p.C;
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = row0 + wr * 128 + mt * 16 + li;
+      const bool live = (row < Mv) && (cb < p.N);     // N % 16 == 0: a lane's 16 columns are all in or all out
+      f32x4 o[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        o[x] = live ? *(f32x4*)(Cf + (long long)row * p.ldc + cb + 4 * x) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < p.splitk; s0 += 4) {      // up to 16 agent-scope loads in flight
+        f32x4 part[4][4];
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const float* wp = p.ws + (((long long)min(s0 + ds, p.splitk - 1) * tpb + id) * 32 + mt * 4) * 2048 + tid * 4;
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(part[ds][x]) : "v"(wp + x * 2048) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+          if (s0 + ds < p.splitk) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              asm volatile("" : "+v"(part[ds][x]));   // value is defined only after the wait above
+              o[x] += part[ds][x];
+            }
+          }
+      }
+      if (live) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) *(f32x4*)(Cf + (long long)row * p.ldc + cb + 4 * x) = o[x];
+      }
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
   }
 }
 
@@ -593,7 +748,7 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.m_valid = m_valid; p.k_valid = k_valid;
   p.act = act; p.out_f32 = out_f32; p.accumulate = accumulate;
-  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0;
+  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
   const int esz = out_f32 ? 4 : 2;
   p.vec_ok = (((uintptr_t)C & 15) == 0) && ((((long long)ldc * esz) & 15) == 0) &&
              (((strideC * esz) & 15) == 0);
@@ -644,7 +799,7 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
   p.batch = batch; p.sA = strideA; p.sB = strideW; p.sC = stride_act;
   p.m_valid = m_valid; p.k_valid = nullptr;
   p.act = 0; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
-  p.C2 = gu_out; p.ldc2 = ld_gu; p.sC2 = stride_gu;
+  p.C2 = gu_out; p.ldc2 = ld_gu; p.sC2 = stride_gu; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
@@ -654,6 +809,90 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
   const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   hipLaunchKernelGGL(gemm_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  return lmod_launch_status();
+}
+
+// Weight-gradient accumulate C (fp32, M x N) += At (M x K) * Bt (N x K)^T for long K (tokens) and few output tiles:
+// deterministic split-K.  `workspace` (16-byte aligned, zeroed ONCE by the caller, used by one stream at a time) holds
+// 16 KiB of tile semaphores followed by up to 8 partial images (256 KiB per 256x256 tile); its size bounds the split.  With a NULL /
+// small workspace, or when splitting does not pay, this is lmod_gemm_bf16_nt(out_f32, accumulate).
+#define WGRAD_MAX_TILES 4096
+static int wgrad_pick_split(int M, int N, int K, int max_s) {
+  if (M < 256 || N < 256 || K < 4096 || (N & 15)) return 1;
+  const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (t256 >= 512 || t256 > WGRAD_MAX_TILES) return 1;
+  int best_s = 1;
+  double best = 1e30;
+  for (int s = 1; s <= max_s; ++s) {
+    const int kc = ((K + s - 1) / s + 63) / 64 * 64;
+    if (kc < 1024) break;
+    const double rounds = (double)((t256 * s + 255) / 256);
+    const double tg = rounds * 131072.0 * kc / 5300.0;                     // ns: one 256x256xkc tile at ~5.3 TF/CU
+    const double ta = (s > 1 ? 2.0 * s + 2.0 : 0.0) * (double)M * N * 4.0 / 2000.0;   // ns: partial write+read, C RMW (measured ~2 TB/s)
+    if (tg + ta < best * 0.97) { best = tg + ta; best_s = s; }
+  }
+  return best_s;
+}
+
+int lmod_gemm_wgrad_bf16_nt(const void* At, const void* Bt, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            void* workspace, long long workspace_bytes, hipStream_t stream) {
+  if (!At || !Bt || !C || M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
+  // the workspace bounds the split: WGRAD_MAX_TILES semaphores (16 KiB) + s partial [M, N] fp32 images
+  long long cap = 0;
+  if (workspace && !((uintptr_t)workspace & 15) && M > 0 && N > 0)
+    cap = (workspace_bytes - (long long)WGRAD_MAX_TILES * 4) / ((long long)((M + 255) / 256) * ((N + 255) / 256) * 262144);
+  int s = wgrad_pick_split(M, N, K, (int)(cap < 1 ? 1 : (cap > 8 ? 8 : cap)));
+  if (s > 1 && (((uintptr_t)C & 15) || (ldc & 3) ||
+                (long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL || (long long)255 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL))
+    s = 1;
+  if (s == 1) return lmod_gemm_bf16_nt(At, Bt, C, nullptr, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, nullptr, nullptr, 0, 1, 1, stream);
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return LMOD_EINVAL;
+  if (((uintptr_t)At & 15) || ((uintptr_t)Bt & 15)) return LMOD_EINVAL;
+  GemmP p;
+  p.A = (const bf16_t*)At; p.B = (const bf16_t*)Bt; p.C = C; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.batch = 1; p.sA = 0; p.sB = 0; p.sC = 0;
+  p.m_valid = nullptr; p.k_valid = nullptr;
+  p.act = 0; p.out_f32 = 1; p.accumulate = 1; p.vec_ok = 1;
+  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0;
+  p.splitk = s; p.kchunk = ((K + s - 1) / s + 63) / 64 * 64;
+  p.counters = (int*)workspace; p.ws = (float*)((char*)workspace + (long long)WGRAD_MAX_TILES * 4);
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * s;
+  hipLaunchKernelGGL(gemm_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  return lmod_launch_status();
+}
+
+// C[b] (M x N) (+)= A[b]^T B[b] with A [K x M] (row stride lda) and B [K x N] (row stride ldb): the weight-gradient
+// form dW = dY^T X on the tensors as autograd holds them (tokens major).  k_valid: live reduction rows per batch
+// (exact, no 8-row granularity).  Split-K: pass batch = S with strideA = Kc*lda, strideB = Kc*ldb and a [S, M, N]
+// workspace as C.  Requires M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned A/B/C, ldc % 4 == 0.
+int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                      long long strideA, long long strideB, long long strideC, const int* k_valid, int out_f32,
+                      int accumulate, hipStream_t stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if ((M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < M || ldb < N || ldc < N || (ldc & 3)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || (strideA & 7) || (strideB & 7) || (strideC & 3))
+    return LMOD_EINVAL;
+  if ((long long)64 * lda * 2 >= 0x7fffffffLL || (long long)64 * ldb * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
+  p.m_valid = nullptr; p.k_valid = k_valid;
+  p.act = 0; p.out_f32 = out_f32; p.accumulate = accumulate; p.vec_ok = 1;
+  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    attr_set = true;
+  }
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  hipLaunchKernelGGL(gemm_256_kernel<2>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   return lmod_launch_status();
 }
 

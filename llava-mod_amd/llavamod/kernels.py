@@ -63,6 +63,40 @@ def gemm_swiglu(x, w_gu, act=None, gu=None, want_gu=False, m_valid=None):
     return act, gu
 
 
+_WGRAD_WS = {}
+WGRAD_WS_BYTES = 512 << 20
+
+
+def gemm_wgrad(at, bt, out):
+    """out (fp32 [M, N]) += at[M, K] @ bt[N, K]^T with deterministic split-K when the output has too few tiles to fill
+    the GPU (K = tokens).  One zero-initialised workspace per device, reused by every call on the compute stream."""
+    key = at.device.index
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.zeros(WGRAD_WS_BYTES, device=at.device, dtype=torch.uint8)
+    M, Kd = at.shape
+    call("lmod_gemm_wgrad_bf16_nt", ptr(at), ptr(bt), ptr(out), M, bt.shape[0], Kd, at.stride(0), bt.stride(0),
+         out.stride(0), ptr(ws), ws.numel())
+    return out
+
+
+def gemm_tn(a, b, out=None, out_f32=True, accumulate=False, k_valid=None, K=None):
+    """out[.., M, N] (+)= a^T @ b with a [.., Kd, M], b [.., Kd, N] (reduction-major: dW = dY^T X without transposes).
+    K: reduce over the first K rows only."""
+    Kd, M = a.shape[-2], a.shape[-1]
+    N = b.shape[-1]
+    if K is not None:
+        Kd = K
+    batch = a.shape[0] if a.dim() == 3 else 1
+    if out is None:
+        out = torch.empty(((batch,) if a.dim() == 3 else ()) + (M, N), device=a.device,
+                          dtype=torch.float32 if out_f32 else BF16)
+    call("lmod_gemm_bf16_tn", ptr(a), ptr(b), ptr(out), M, N, Kd, a.stride(-2), b.stride(-2), out.stride(-2), batch,
+         a.stride(0) if a.dim() == 3 else 0, b.stride(0) if b.dim() == 3 else 0, out.stride(0) if out.dim() == 3 else 0,
+         ptr(k_valid), int(out_f32), int(accumulate))
+    return out
+
+
 def transpose(x, ld_out=None, out=None):
     """[.., R, C] -> [.., C, roundup(R,8)] (zero padded)."""
     R, C = x.shape[-2], x.shape[-1]

@@ -148,7 +148,7 @@ def linear_wgrad(dy, x, fw):
     """main_grad += dy^T @ x ; bias main_grad += colsum(dy)."""
     dyt = K.transpose(dy)                     # [N, Tpad]
     xt = K.transpose(x)                       # [K, Tpad]
-    K.gemm_nt(dyt, xt, out=fw.grad_buffer(), out_f32=True, accumulate=True)
+    K.gemm_wgrad(dyt, xt, fw.grad_buffer())
     if fw.bias_requires_grad:
         tmp = K.gemm_nt(dyt, _ones(dyt.shape[1], dy.device), out_f32=True)      # [N, 8]; every column = token sum
         fw.bias_grad_buffer().add_(tmp[:, 0])

@@ -142,6 +142,55 @@ def test_gemm_grouped_valid_rows():
         close(dw[e], ref, f"k_valid e{e}", rtol=1e-4, afrac=1e-5)
 
 
+@pytest.mark.parametrize("Kd,M,N", [(64, 8, 8), (300, 136, 264), (1000, 520, 256), (4096, 512, 1032)])
+def test_gemm_tn_wgrad_form(Kd, M, N):
+    # C = A^T B on reduction-major operands (dW = dY^T X), fp32 out / accumulate / bf16 out, strided views
+    a_full, b_full = rnd(Kd, M + 16, seed=40), rnd(Kd, N + 8, seed=41)
+    a, b = a_full[:, 8:8 + M], b_full[:, :N]                      # column sub-views: lda > M, 16-byte aligned offset
+    ref = a.float().t() @ b.float()
+    close(K.gemm_tn(a, b), ref, f"tn {Kd}x{M}x{N}", rtol=1e-4, afrac=1e-5)
+    acc = torch.full((M, N), 3.0, device=DEV, dtype=torch.float32)
+    K.gemm_tn(a, b, out=acc, accumulate=True)
+    close(acc, ref + 3.0, "tn accumulate", rtol=1e-4, afrac=1e-5)
+    close(K.gemm_tn(a, b, out_f32=False), ref, "tn bf16 out")
+    # asymmetric check against a transposed / permuted write: A = one-hot rows
+    eye = torch.zeros(Kd, M, device=DEV, dtype=BF)
+    idx = torch.arange(min(Kd, M), device=DEV)
+    eye[idx, idx] = 1
+    got = K.gemm_tn(eye, b)
+    assert torch.equal(got[:min(Kd, M)], b[:min(Kd, M)].float()), "layout"
+
+
+def test_gemm_tn_batched_kvalid_and_splitk():
+    E, C, H, I = 4, 200, 136, 264
+    dy, x = rnd(E, C, I, seed=42), rnd(E, C, H, seed=43)
+    kv = torch.tensor([200, 0, 77, 130], device=DEV, dtype=torch.int32)
+    dw = K.gemm_tn(dy, x, k_valid=kv)
+    for e in range(E):
+        n = int(kv[e])
+        close(dw[e], dy[e, :n].float().t() @ x[e, :n].float(), f"tn k_valid e{e}", rtol=1e-4, afrac=1e-5)
+    # split-K through the batch dimension: 4 chunks of 256 rows into a [4, M, N] workspace
+    a, b = rnd(1024, 264, seed=44), rnd(1024, 136, seed=45)
+    ws = K.gemm_tn(a.view(4, 256, 264), b.view(4, 256, 136))
+    close(ws.sum(0), a.float().t() @ b.float(), "tn split-K", rtol=1e-4, afrac=1e-5)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(512, 512, 8192), (2048, 256, 4096 + 64), (264, 272, 5000 // 8 * 8), (128, 64, 512)])
+def test_gemm_wgrad_splitk_deterministic(M, N, Kd):
+    # fp32 accumulate with split-K through the tile semaphores: right answer, and bit-identical run to run
+    at, bt = rnd(M, Kd, seed=50), rnd(N, Kd, seed=51)
+    ref = at.float() @ bt.float().t()
+    outs = []
+    for _ in range(3):
+        g = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+        K.gemm_wgrad(at, bt, g)
+        outs.append(g)
+    close(outs[0], ref + 0.5, f"wgrad split-K {M}x{N}x{Kd}", rtol=1e-4, afrac=1e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split-K must not depend on arrival order"
+    K.gemm_wgrad(at, bt, outs[0])                      # accumulates on top
+    close(outs[0], 2 * ref + 0.5, "wgrad accumulate twice", rtol=1e-4, afrac=1e-5)
+
+
 def test_transpose():
     for (R, C) in [(64, 64), (100, 72), (7, 8), (513, 1032)]:
         x = rnd(R, C, seed=R)
