@@ -77,8 +77,11 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         return self._head.ensure()
 
     # ---- internal fast path -------------------------------------------------------------------
-    def forward_hidden(self, input_ids=None, attention_mask=None, labels=None, images=None, inputs_embeds=None):
-        """Splice + decoder.  Returns (hidden [B*S', H], moe_loss_list, info) — no logits."""
+    def forward_hidden(self, input_ids=None, attention_mask=None, labels=None, images=None, inputs_embeds=None,
+                       plan_fn=None):
+        """Splice + decoder.  Returns (hidden [B*S', H], moe_loss_list, info) — no logits.
+        plan_fn(info) -> loss plan (no-grad forwards only): the decoder then returns just the plan's rows
+        ([R, H], `info.plan.pregathered`), letting the last layer skip the rows nobody reads."""
         if inputs_embeds is None:
             _, _, attention_mask, _, inputs_embeds, labels = self.prepare_inputs_labels_for_multimodal(
                 input_ids, None, attention_mask, None, labels, images)
@@ -99,14 +102,20 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             lens = attention_mask.to(torch.int32).sum(1)
             if bool((lens != S).any()):
                 seqlens = lens.to(device=inputs_embeds.device, dtype=torch.int32).contiguous()
-        hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens)
         if labels is not None:
             labels_np = plan.labels_np if plan is not None else labels.detach().cpu().numpy()
         else:
             labels_np = None
         lens_np = plan.lens_np if plan is not None else None
-        return hidden, moe_list, SimpleNamespace(B=B, S=S, labels=labels, labels_np=labels_np, lens_np=lens_np,
-                                                 attention_mask=attention_mask)
+        info = SimpleNamespace(B=B, S=S, labels=labels, labels_np=labels_np, lens_np=lens_np,
+                               attention_mask=attention_mask, plan=None)
+        out_rows = None
+        if plan_fn is not None and labels_np is not None and not torch.is_grad_enabled():
+            info.plan = plan_fn(info)
+            info.plan.pregathered = True
+            out_rows = info.plan.row_idx
+        hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens, out_rows=out_rows)
+        return hidden, moe_list, info
 
     def lm_loss_from_hidden(self, hidden, info):
         """Shifted CrossEntropyLoss() of the reference forward (mean over non-ignored), loss rows only."""

@@ -123,6 +123,12 @@ class FusedWeight:
             r += bp.shape[0]
 
 
+def _need(ctx):
+    """Might this Function's backward run?  (Grad mode is always off inside Function.forward, so under an outer
+    torch.no_grad() this can still say True for unfrozen parameters; the saved tensors are then simply dropped.)"""
+    return any(ctx.needs_input_grad)
+
+
 _ONES = {}
 
 
@@ -188,12 +194,15 @@ class AttnBlock(torch.autograd.Function):
         qkv = linear_fwd(x, spec.qkv)
         K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
-        need = any(ctx.needs_input_grad)
+        rows = getattr(spec, "rows", None)      # set only by no-grad forwards (Qwen2Model.forward checks the grad mode)
+        need = _need(ctx) and rows is None
         if need:
             for fw in (spec.qkv, spec.o):
                 if fw.requires_grad:
                     fw.note_use()
         o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need)
+        if rows is not None:                  # last layer of a no-grad forward: only these token rows are consumed
+            o = K.gather_rows(o, None, rows, o.shape[1])
         out = linear_fwd(o, spec.o)
         ctx.spec = spec
         if need:
@@ -227,7 +236,7 @@ class MLPBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, spec, *params):
-        need = any(ctx.needs_input_grad)
+        need = _need(ctx)
         if spec.gu.b is None:
             act, gu = K.gemm_swiglu(x, spec.gu.w, want_gu=need)
         else:
@@ -282,7 +291,7 @@ class ProjectorBlock(torch.autograd.Function):
         mid = K.gelu_fwd(pre)
         out = linear_fwd(mid, spec.fc2)
         ctx.spec = spec
-        if any(ctx.needs_input_grad):
+        if _need(ctx):
             ctx.save_for_backward(feats, pre)
             for fw in (spec.fc1, spec.fc2):
                 if fw.requires_grad:
@@ -341,7 +350,7 @@ class MoEBlock(torch.autograd.Function):
         rows = st.slots_used
         disp = K.gather_rows(x, None, st.slot_token, H)                       # [E*C, H], zero rows on empty slots
         I = spec.gu.w.shape[1] // 2
-        need = any(ctx.needs_input_grad)
+        need = _need(ctx)
         # grouped gate/up GEMM with SwiGLU in the epilogue (dead rows up to the next multiple of 8 are zeroed in act)
         act, gu = K.gemm_swiglu(disp.view(E, C, H), spec.gu.w, want_gu=need, m_valid=rows)
         y = torch.empty((E, C, H), device=x.device, dtype=BF16)
@@ -408,7 +417,7 @@ class DistillHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hidden, head, plan, teacher_logits, *params):
         H = hidden.shape[1]
-        rows = K.gather_rows(hidden, None, plan.row_idx, H)                    # [R, H]
+        rows = hidden if getattr(plan, "pregathered", False) else K.gather_rows(hidden, None, plan.row_idx, H)   # [R, H]
         logits = linear_fwd(rows, head)                                         # [R, Vs] bf16
         Vs = head.w.shape[0]
         Va = plan.align_vocab if teacher_logits is not None else Vs
@@ -416,7 +425,7 @@ class DistillHead(torch.autograd.Function):
         kd_sum, kd_cnt = K.segment_wsum(stats, 3, plan.kd_w, plan.seg_off)
         ce_sum, ce_cnt = K.segment_wsum(stats, 4, plan.ce_w, plan.seg_off)
         ctx.head, ctx.plan, ctx.Va = head, plan, Va
-        if any(ctx.needs_input_grad):
+        if _need(ctx):
             ctx.save_for_backward(logits, stats, teacher_logits, rows if head.requires_grad else None)
             if head.requires_grad:
                 head.note_use()
@@ -450,7 +459,7 @@ class Linear(torch.autograd.Function):
     def forward(ctx, x, fw, *params):
         y = linear_fwd(x, fw)
         ctx.fw = fw
-        if any(ctx.needs_input_grad):
+        if _need(ctx):
             ctx.save_for_backward(x if fw.requires_grad else None)
             if fw.requires_grad:
                 fw.note_use()
@@ -556,7 +565,7 @@ class ExpertFFN(torch.autograd.Function):
     def forward(ctx, x, spec, rows, *params):
         ep, El, C, H = x.shape
         I = spec.gu.w.shape[-2] // 2
-        need = any(ctx.needs_input_grad)
+        need = _need(ctx)
         gu = torch.empty((ep, El, C, 2 * I), device=x.device, dtype=BF16) if need else None
         act = torch.zeros((ep, El, C, I), device=x.device, dtype=BF16)    # dead rows stay zero (wgrad reads whole slabs)
         for le in range(El):          # one grouped launch per local expert: batch = source ranks, shared weights

@@ -11,6 +11,8 @@ Trainer / DeepSpeed control plane around it is out of scope (llavamod.engine dri
 from collections import defaultdict
 from types import SimpleNamespace
 
+import copy
+
 import torch
 
 from .. import kernels as K
@@ -41,16 +43,21 @@ class AlignTrainer:
                                distill_all_tokens=getattr(self.args, "distill_all_tokens", False), align_vocab=Va,
                                device=device)
 
+    def _dev(self):
+        return next(self.ref_model.parameters()).device
+
     def compute_loss(self, model, inputs, return_outputs=False):
         assert self.ref_model is not None, "ref model can not be none!"
         batch = dict(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
                      labels=inputs.get("labels"), images=inputs.get("images"))
         with torch.no_grad():                                  # teacher forward (:556-560)
-            t_hidden, _, t_info = self.ref_model.forward_hidden(**batch)
-            plan = self._plan(t_info, t_hidden.device)
-            t_rows = K.gather_rows(t_hidden, None, plan.row_idx, t_hidden.shape[1])
+            # the teacher only feeds the loss rows: its last layer and lm_head run on those rows alone
+            t_rows, _, t_info = self.ref_model.forward_hidden(**batch, plan_fn=lambda info: self._plan(info, self._dev()))
+            teacher_plan = t_info.plan
             t_logits = ops.linear_fwd(t_rows, self.ref_model.head())          # [R, Vt] bf16, loss rows only
-            del t_hidden, t_rows
+            del t_rows
+        plan = copy.copy(teacher_plan)
+        plan.pregathered = False                               # the student's hidden states stay [T, H] (it has a backward)
         s_hidden, moe_list, _ = model.forward_hidden(**batch)                  # student forward (:562)
         kd_sum, kd_cnt, ce_sum, ce_cnt = ops.DistillHead.apply(s_hidden, model.head(), plan, t_logits,
                                                                *model._head_trainable())

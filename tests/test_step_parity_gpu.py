@@ -281,3 +281,23 @@ def test_materialising_api_matches_oracle():
     assert (lp.cpu() - ref_lp).abs().max() < 2e-2
     ref_al = olosses.compute_align_loss(ref_lp, ref_p, g["plain.labels"])
     assert abs(float(al) - float(ref_al)) <= 1e-3 * abs(float(ref_al))
+
+
+def test_teacher_row_trimmed_forward_is_exact():
+    """no-grad forward with a loss plan returns only the plan's rows, bit-identical to gathering the full forward."""
+    from llavamod.model.language_model.llava_qwen2 import build_loss_plan
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    _, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    batch = _batch_from(g, "ragged_kdlm")
+    mk = lambda info: build_loss_plan(info.labels_np, info.lens_np, device=DEV)
+    with torch.no_grad():
+        full, _, info = teacher.forward_hidden(**batch)
+        plan = mk(info)
+        rows, _, info2 = teacher.forward_hidden(**batch, plan_fn=mk)
+    assert info2.plan.pregathered and rows.shape == (plan.R, full.shape[1]) and plan.R < full.shape[0]
+    assert torch.equal(rows, full[plan.row_idx.long()])
+    # with autograd on, the plan is ignored and every row comes back
+    full2, _, info3 = teacher.forward_hidden(**batch, plan_fn=mk)
+    assert info3.plan is None and full2.shape == full.shape
