@@ -80,8 +80,8 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
     def forward_hidden(self, input_ids=None, attention_mask=None, labels=None, images=None, inputs_embeds=None,
                        plan_fn=None):
         """Splice + decoder.  Returns (hidden [B*S', H], moe_loss_list, info) — no logits.
-        plan_fn(info) -> loss plan (no-grad forwards only): the decoder then returns just the plan's rows
-        ([R, H], `info.plan.pregathered`), letting the last layer skip the rows nobody reads."""
+        plan_fn(info) -> loss plan: the decoder then returns just the plan's rows ([R, H], `info.plan.pregathered`),
+        letting a dense last layer skip (forward and backward) the rows nobody reads."""
         if inputs_embeds is None:
             _, _, attention_mask, _, inputs_embeds, labels = self.prepare_inputs_labels_for_multimodal(
                 input_ids, None, attention_mask, None, labels, images)
@@ -109,12 +109,13 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         lens_np = plan.lens_np if plan is not None else None
         info = SimpleNamespace(B=B, S=S, labels=labels, labels_np=labels_np, lens_np=lens_np,
                                attention_mask=attention_mask, plan=None)
-        out_rows = None
-        if plan_fn is not None and labels_np is not None and not torch.is_grad_enabled():
+        out_rows = inv_rows = None
+        if plan_fn is not None and labels_np is not None:
             info.plan = plan_fn(info)
             info.plan.pregathered = True
-            out_rows = info.plan.row_idx
-        hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens, out_rows=out_rows)
+            out_rows, inv_rows = info.plan.row_idx, info.plan.inv_row_idx
+        hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens, out_rows=out_rows,
+                                      inv_rows=inv_rows)
         return hidden, moe_list, info
 
     def lm_loss_from_hidden(self, hidden, info):

@@ -79,10 +79,10 @@ class Qwen2Attention(nn.Module):
     def trainable(self):
         return [p for p in self.parameters() if p.requires_grad]
 
-    def forward(self, x, rt, rows=None):
+    def forward(self, x, rt, rows=None, inv_rows=None):
         spec = SimpleNamespace(qkv=self._qkv.ensure(), o=self._o.ensure(), B=rt.B, S=rt.S, nh=self.nh, nkv=self.nkv,
                                hd=self.hd, cos=rt.cos, sin=rt.sin, pos=rt.pos, scale=1.0 / math.sqrt(self.hd),
-                               seqlens=rt.seqlens, rows=rows)
+                               seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows)
         return ops.AttnBlock.apply(x, spec, *self.trainable())
 
 
@@ -128,13 +128,14 @@ class Qwen2DecoderLayer(nn.Module):
             m = m[0]
         return m, h2, moe_losses
 
-    def forward_rows(self, delta, res, rt, rows):
-        """Same layer, but everything after the attention core runs only on token rows `rows` (int32 [R]): the last
-        layer of a forward whose consumer reads R << T rows (loss rows of a frozen teacher).  Dense MLP, no-grad only
-        (a MoE layer's capacity and l_aux depend on every token)."""
+    def forward_rows(self, delta, res, rt, rows, inv_rows):
+        """Same layer, but everything after the attention core runs only on token rows `rows` (int32 [R]; inv_rows[t] =
+        position of t in rows or -1): the LAST layer of a model whose consumer reads R << T rows (the loss rows).  The
+        values on those rows, and every gradient, are the same as computing all rows.  Dense MLP only (a MoE layer's
+        capacity and l_aux depend on every token)."""
         n1, h = ops.AddRMSNorm.apply(delta, res, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
-        a = self.self_attn(n1, rt, rows=rows)                                      # [R, H]
-        h_r = K.gather_rows(h, None, rows, h.shape[1])
+        a = self.self_attn(n1, rt, rows=rows, inv_rows=inv_rows)                    # [R, H]
+        h_r = ops.RowGather.apply(h, rows, inv_rows)
         n2, h2 = ops.AddRMSNorm.apply(a, h_r, self.post_attention_layernorm.weight,
                                       self.post_attention_layernorm.variance_epsilon)
         return self.mlp(n2, rt), h2
@@ -168,24 +169,24 @@ class Qwen2Model(nn.Module):
         pos = torch.arange(S, device=device, dtype=torch.int32).repeat(B)          # position_ids = arange(S')
         return SimpleNamespace(B=B, S=S, cos=cos, sin=sin, pos=pos, seqlens=seqlens)
 
-    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None):
-        """inputs_embeds: [B*S, H].  Returns (final-normed hidden [B*S, H], list of l_aux).  out_rows (int32 [R],
-        no-grad forwards only): return just those rows, [R, H] — the last layer then skips o_proj / MLP / norm work on
-        every other row (identical values on the rows returned)."""
+    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None, inv_rows=None):
+        """inputs_embeds: [B*S, H].  Returns (final-normed hidden [B*S, H], list of l_aux).  out_rows (int32 [R]) with
+        inv_rows (int32 [B*S]): return just those rows, [R, H] — a dense last layer then skips o_proj / MLP / norm work
+        (forward and backward) on every other row."""
         rt = self.runtime(B, S, seqlens, inputs_embeds.device)
         delta, res = inputs_embeds, None
         all_moe = []
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            if i == last and out_rows is not None and type(layer.mlp) is Qwen2MLP and not torch.is_grad_enabled():
-                delta, res = layer.forward_rows(delta, res, rt, out_rows)
+            if i == last and out_rows is not None and type(layer.mlp) is Qwen2MLP:
+                delta, res = layer.forward_rows(delta, res, rt, out_rows, inv_rows)
                 out_rows = None
                 continue
             delta, res, ml = layer(delta, res, rt)
             all_moe.extend(ml)
-        if out_rows is not None:               # could not trim inside the last layer: gather at the end
-            delta = K.gather_rows(delta, None, out_rows, delta.shape[1])
-            res = K.gather_rows(res, None, out_rows, res.shape[1]) if res is not None else None
+        if out_rows is not None:               # sparse last layer: every row is needed inside it; select at the end
+            delta = ops.RowGather.apply(delta, out_rows, inv_rows)
+            res = ops.RowGather.apply(res, out_rows, inv_rows) if res is not None else None
         y, _ = ops.AddRMSNorm.apply(delta, res, self.norm.weight, self.norm.variance_epsilon)
         return y, all_moe
 

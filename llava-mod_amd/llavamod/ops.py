@@ -182,6 +182,20 @@ class AddRMSNorm(torch.autograd.Function):
         return g, (g if ctx.has_res else None), None, None
 
 
+# ------------------------------------------------------------------------------------------ row selection
+class RowGather(torch.autograd.Function):
+    """x[T,H] -> x[rows] ([R,H]); backward scatters into zeros (inv[t] = position of row t in `rows`, or -1)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, inv):
+        ctx.inv = inv
+        return K.gather_rows(x, None, rows, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.gather_rows(dy.contiguous(), None, ctx.inv, dy.shape[1]), None, None
+
+
 # ------------------------------------------------------------------------------------------ attention block
 class AttnBlock(torch.autograd.Function):
     """x[T,H] -> o_proj(attention(rope(qkv_proj(x)))).  Decoder self-attention of
@@ -194,30 +208,31 @@ class AttnBlock(torch.autograd.Function):
         qkv = linear_fwd(x, spec.qkv)
         K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
-        rows = getattr(spec, "rows", None)      # set only by no-grad forwards (Qwen2Model.forward checks the grad mode)
-        need = _need(ctx) and rows is None
+        rows = getattr(spec, "rows", None)      # last layer of a model whose consumer reads only these token rows
+        need = _need(ctx)
         if need:
             for fw in (spec.qkv, spec.o):
                 if fw.requires_grad:
                     fw.note_use()
         o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need)
-        if rows is not None:                  # last layer of a no-grad forward: only these token rows are consumed
-            o = K.gather_rows(o, None, rows, o.shape[1])
-        out = linear_fwd(o, spec.o)
+        o_in = K.gather_rows(o, None, rows, o.shape[1]) if rows is not None else o    # o_proj on [R, nh*hd] only
+        out = linear_fwd(o_in, spec.o)
         ctx.spec = spec
         if need:
-            ctx.save_for_backward(x if spec.qkv.requires_grad else None, qkv, o, lse)
+            ctx.save_for_backward(x if spec.qkv.requires_grad else None, qkv, o, lse, o_in if rows is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         sp = ctx.spec
-        x, qkv, o, lse = ctx.saved_tensors
+        x, qkv, o, lse, o_rows = ctx.saved_tensors
         nh, nkv, hd = sp.nh, sp.nkv, sp.hd
         dout = dout.contiguous()
         do = linear_dgrad(dout, sp.o)
         if sp.o.requires_grad:
-            linear_wgrad(dout, o, sp.o)
+            linear_wgrad(dout, o if o_rows is None else o_rows, sp.o)
+        if o_rows is not None:                # scatter the row gradients back to [T, nh*hd] (zeros elsewhere)
+            do = K.gather_rows(do, None, sp.inv_rows, do.shape[1])
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
@@ -447,7 +462,10 @@ class DistillHead(torch.autograd.Function):
         d_rows = linear_dgrad(logits, head)
         if head.requires_grad:
             linear_wgrad(logits, rows, head)
-        dh = K.gather_rows(d_rows, None, plan.inv_row_idx, d_rows.shape[1])    # scatter back, zeros elsewhere
+        if getattr(plan, "pregathered", False):
+            dh = d_rows                                                         # hidden arrived as [R, H]
+        else:
+            dh = K.gather_rows(d_rows, None, plan.inv_row_idx, d_rows.shape[1])   # scatter back, zeros elsewhere
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 

@@ -56,9 +56,9 @@ class AlignTrainer:
             teacher_plan = t_info.plan
             t_logits = ops.linear_fwd(t_rows, self.ref_model.head())          # [R, Vt] bf16, loss rows only
             del t_rows
-        plan = copy.copy(teacher_plan)
-        plan.pregathered = False                               # the student's hidden states stay [T, H] (it has a backward)
-        s_hidden, moe_list, _ = model.forward_hidden(**batch)                  # student forward (:562)
+        # same inputs => same spliced labels => same loss rows: the student's last (dense) layer is trimmed the same way
+        s_hidden, moe_list, s_info = model.forward_hidden(**batch, plan_fn=lambda info: copy.copy(teacher_plan))
+        plan = s_info.plan
         kd_sum, kd_cnt, ce_sum, ce_cnt = ops.DistillHead.apply(s_hidden, model.head(), plan, t_logits,
                                                                *model._head_trainable())
         align_loss = -(kd_sum.sum() / kd_cnt.sum())                            # :526

@@ -54,7 +54,7 @@ class DPOTrainer:
         """(sum_t log p(y_t) over labelled shifted positions [B], sft_loss, moe_loss) — dpo_trainer.py:462-495."""
         dev = next(model.parameters()).device
         mk = lambda info: build_loss_plan(info.labels_np, info.lens_np, kd_rows=False, ce_rows=True, device=dev)
-        # under no_grad (the frozen reference model) only the loss rows leave the decoder
+        # only the loss rows leave the decoder (a dense last layer skips the other rows, forward and backward)
         hidden, moe_list, info = model.forward_hidden(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
                                                       labels=inputs.get("labels"), images=inputs.get("images"), plan_fn=mk)
         plan = info.plan if info.plan is not None else mk(info)

@@ -298,6 +298,18 @@ def test_teacher_row_trimmed_forward_is_exact():
         rows, _, info2 = teacher.forward_hidden(**batch, plan_fn=mk)
     assert info2.plan.pregathered and rows.shape == (plan.R, full.shape[1]) and plan.R < full.shape[0]
     assert torch.equal(rows, full[plan.row_idx.long()])
-    # with autograd on, the plan is ignored and every row comes back
-    full2, _, info3 = teacher.forward_hidden(**batch, plan_fn=mk)
-    assert info3.plan is None and full2.shape == full.shape
+    # with autograd on the same rows come back, and the gradient w.r.t. the inputs equals the untrimmed one
+    emb = torch.randn(full.shape[0], teacher.config.hidden_size, device=DEV).to(torch.bfloat16)
+    B, S = info.B, info.S
+    grads = []
+    for trimmed in (False, True):
+        e = emb.clone().requires_grad_(True)
+        if trimmed:
+            y, _ = teacher.model(e, B, S, None, out_rows=plan.row_idx, inv_rows=plan.inv_row_idx)
+        else:
+            y, _ = teacher.model(e, B, S, None)
+            y = y[plan.row_idx.long()]
+        w = torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)
+        (y.float() * w).sum().backward()
+        grads.append(e.grad.float())
+    assert U.relerr(grads[1], grads[0]) < 2e-2, U.relerr(grads[1], grads[0])
