@@ -90,9 +90,13 @@ def mimic_tflop(t_layers=32, s_dense=12, s_moe=12, vit_layers=23, S=2048, head_r
     return (teacher + s_fwd + s_dgrad + s_wgrad + 2 * vit) / 1e12
 
 
-def executed_tflop_per_sample():
-    """What this implementation issues: lm_head GEMMs (teacher fwd, student fwd + dgrad) on the 513 loss rows."""
-    return mimic_tflop(head_rows=513)
+def executed_tflop_per_sample(S=2048, rows=513):
+    """What this implementation issues: lm_head GEMMs (teacher fwd, student fwd + dgrad) and the o_proj + MLP of each
+    model's LAST (dense) decoder layer on the 513 loss rows only."""
+    skipped = S - rows
+    t_last = skipped * (2 * 4096 * 4096 + 6 * 4096 * 11008)                       # teacher: forward only
+    s_last = skipped * (2 * (2 * 2048 * 2048 + 6 * 2048 * 5504) + 6 * 2048 * 5504)  # student: fwd + dgrad (+ FFN wgrad)
+    return mimic_tflop(head_rows=rows) - (t_last + s_last) / 1e12
 
 
 def cpu_baseline():
@@ -209,10 +213,12 @@ def main():
         sps = args.steps * B * world / dt
         ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
         achieved = ledger * sps / world
-        # dominant kernel, measured live with HIP events on the launch stream (torch's current stream):
-        a = torch.randn(B * 2048, 4096, device=dev).to(torch.bfloat16)
-        w = torch.randn(22016, 4096, device=dev).to(torch.bfloat16)
-        o = torch.empty(B * 2048, 22016, device=dev, dtype=torch.bfloat16)
+        # dominant kernel (gemm_256_kernel<0>, ~51 % of GPU time in profiles/) at the shape it spends most time on —
+        # the teacher's fused QKV projection — measured live with HIP events on the launch stream (torch's current stream)
+        gm, gn, gk = B * 2048, 12288, 4096
+        a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
+        w = torch.randn(gn, gk, device=dev).to(torch.bfloat16)
+        o = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
         for _ in range(2):
             K.gemm_nt(a, w, out=o)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -222,7 +228,16 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         gemm_ms = e0.elapsed_time(e1) / 10
-        gemm_tf = 2.0 * B * 2048 * 22016 * 4096 / (gemm_ms * 1e-3) / 1e12
+        gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
+        traffic, traffic_note = None, "no committed PMC pass for this shape"
+        tp = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            if tj["shape"] == [gm, gn, gk]:
+                traffic = round((tj["fetch_bytes_corrected"] + tj["write_bytes"]) / 1e9, 2)
+                traffic_note = (f"GB per launch at the L2/fabric boundary (Infinity-Cache hits included), {tj['source']}; "
+                                f"algorithmic {tj['algorithmic_bytes'] / 1e9:.2f} GB — see profiles/r01_final_pmc.md")
         out = {
             "metric": "distillation samples/sec (336px img + 2k ctx), 2B-MoE student / 7B teacher",
             "value": round(sps, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,10 +252,10 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            # dominant kernel (71 % of GPU time in profiles/): gemm_256_kernel<0> (NT GEMM) at its largest shape, timed live above
-            "roofline": {"bound": "mfma", "kernel": f"gemm_256_kernel<0> (bf16 NT GEMM, 256x256x64 tiles) @ [{B * 2048}x22016x4096]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_256_kernel<0> (bf16 NT GEMM, 256x256x64 tiles) @ teacher QKV [{gm}x{gn}x{gk}]",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(gemm_ms, 4),
+                         "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "launch_ms": round(gemm_ms, 4),
                          "whole_step": {"achieved": round(achieved, 1), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                                         "basis": f"{ledger:.2f} algorithmic TFLOP per unit (BASELINE.md) x units/s / n_gpus",
                                         "executed_tflop_per_sample": round(executed_tflop_per_sample(), 2)}},

@@ -29,6 +29,12 @@
 #define NWAVE 8
 #endif
 #define NTHR (NWAVE * 64)
+#ifndef ATT_SCHED
+#define ATT_SCHED 1
+#endif
+#ifndef ATT_PRIO
+#define ATT_PRIO 1
+#endif
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
@@ -260,7 +266,7 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
     // ---------------- interval X
     if (grp == 0 && j + 1 < ntiles) prefetch(j + 1);
     if (active) {
-      __builtin_amdgcn_s_setprio(1);
+      if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 q0f = read_rows<HD, 0>(sQ, wave * 32 + li, ks * 4 + g);
@@ -272,9 +278,9 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
           s[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q0f, ks == 0 ? zero4 : s[0][nt], 0, 0, 0);
           s[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q1f, ks == 0 ? zero4 : s[1][nt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting every operand read of the tile (spills)
+        if (ATT_SCHED) __builtin_amdgcn_sched_barrier(0);      // keep hipcc from hoisting every operand read of the tile (spills)
       }
-      __builtin_amdgcn_s_setprio(0);
+      if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);
       if (need_mask) softmax(BoolTag<true>{}, 0); else softmax(BoolTag<false>{}, 0);
     }
     if (grp == 1 && j + 1 < ntiles) commit(j + 1);
@@ -283,7 +289,7 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
     if (grp == 1 && j + 2 < ntiles) prefetch(j + 2);
     if (active) {
       if (need_mask) softmax(BoolTag<true>{}, 1); else softmax(BoolTag<false>{}, 1);
-      __builtin_amdgcn_s_setprio(1);
+      if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -291,9 +297,9 @@ __device__ __forceinline__ void attn_fwd_block(const AttnP& p, char* smem, int q
           const bf16x8 vf = read_tr<HD, 2>(sV, d, st, lane);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) o[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][st], o[qt][d], 0, 0, 0);
-          if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          if (ATT_SCHED && (d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-      __builtin_amdgcn_s_setprio(0);
+      if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (grp == 0 && j + 1 < ntiles) commit(j + 1);
     ATT_BARRIER();

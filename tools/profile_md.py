@@ -1,0 +1,108 @@
+"""Turn rocprofv3 outputs under gpurun_out/<run>/ into the markdown summaries committed under profiles/.
+usage: python tools/profile_md.py gpurun_out/final profiles/r01_final"""
+import collections, csv, glob, json, os, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def stats_md():
+    rows = list(csv.DictReader(open(f"{src}/bench/a_kernel_stats.csv")))
+    trace = list(csv.DictReader(open(f"{src}/bench/a_kernel_trace.csv")))
+    line = json.loads(open(f"{src}/bench_line.json").read())
+    n_steps = line["steps"] + line["warmup"]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = ["# rocprofv3 --kernel-trace --stats of the default bench workload (round 1, final)", "",
+           "Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
+           "--no-cpu-baseline`", "",
+           f"{n_steps} steps (1 warm-up + 3 timed), micro-batch {line['config']['micro_batch_per_gpu']}, config 2.  Sum of kernel "
+           f"time {tot / 1e6:.1f} ms = {tot / 1e6 / n_steps:.1f} ms/step; bench wall clock under the profiler "
+           f"{line['ms_per_step']} ms/step ({line['value']} samples/s).  Model construction is inside the trace (torch "
+           "`distribution_elementwise` / `copyBuffer` rows).", "",
+           "| kernel | calls | total ms | % | avg us | min us | max us |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:32]:
+        out.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['Percentage']):.1f} | "
+                   f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} |")
+    # the bench's live-timed launches: gemm_256_kernel<0> with the teacher-QKV grid (128 x 48 tiles)
+    gm = line["config"]["micro_batch_per_gpu"] * 2048
+    blocks = (gm // 256) * (12288 // 256)
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
+         if "gemm_256_kernel<0>" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // 512 == blocks]
+    rl = line["roofline"]
+    out += ["", "## Dominant kernel cross-check", "",
+            f"`gemm_256_kernel<0>` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
+            f"trace (32 per step inside the teacher + the 12 that bench.py times with HIP events), average {sum(d) / len(d):.1f} us, "
+            f"min {min(d):.1f}, max {max(d):.1f}.  bench.py's live HIP-event figure in the same run: {rl['launch_ms'] * 1e3:.1f} us "
+            f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak)."]
+    by = collections.defaultdict(lambda: [0, 0.0])
+    for r in trace:
+        if "gemm_256_kernel" in r["Kernel_Name"]:
+            k = (r["Kernel_Name"][5:23], int(r["Grid_Size_X"]) // 512)
+            by[k][0] += 1; by[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    out += ["", "## 256-tile GEMM launches by grid size (workgroups; 256 CUs => `waves` rounds)", "",
+            "| kernel | workgroups | rounds | calls | total ms |", "|---|---|---|---|---|"]
+    for (k, nb), (n, ms) in sorted(by.items(), key=lambda t: -t[1][1])[:16]:
+        out.append(f"| `{k}` | {nb} | {nb / 256:.2f} | {n} | {ms:.1f} |")
+    open(dst + "_bench_kernel_stats.md", "w").write("\n".join(out) + "\n")
+    json.dump(line, open(dst + "_bench_n1.json", "w"), indent=1)
+
+
+def pmc(run):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    for f in glob.glob(f"{src}/{run}/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:40]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    dur = collections.defaultdict(list)
+    for f in glob.glob(f"{src}/{run}/*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"][:40]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return {k: ({c: v / len(disp[k]) for c, v in cs.items()}, sum(dur[k]) / max(1, len(dur[k]))) for k, cs in agg.items()}
+
+
+def pmc_md():
+    out = ["# PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only) — round 1, final", "",
+           "Per-dispatch averages.  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles; "
+           "`SQ_VALU_MFMA_BUSY_CYCLES` counts cycles summed over the 1024 SIMDs; `GRBM_GUI_ACTIVE` is summed over the 8 XCDs.", ""]
+    g = pmc("gemm_sq"); f = pmc("gemm_fetch"); w = pmc("gemm_write")
+    k = next(x for x in g if "gemm_256" in x)
+    c, us = g[k]
+    fetch_kb, write_kb = f[k][0]["FETCH_SIZE"], w[k][0]["WRITE_SIZE"]
+    M, N, Kd = 32768, 12288, 4096
+    algo = (M * Kd + N * Kd + M * N) * 2
+    clk = c["GRBM_GUI_ACTIVE"] / 8 / us / 1e3
+    out += [f"## `gemm_256_kernel<0>` at the teacher QKV shape [{M} x {N} x {Kd}] (`python tools/gemm_one.py`)", "",
+            f"* duration under the counter passes: {us:.0f} us ({2.0 * M * N * Kd / us / 1e6:.0f} TFLOP/s; counter collection and its lower "
+            f"clock cost ~10 % against the un-profiled {2.0 * M * N * Kd / 1e12:.2f} TFLOP launch in bench.py)",
+            f"* effective clock: GRBM_GUI_ACTIVE / 8 / duration = **{clk:.2f} GHz** (peak 2.4): the chip is power-limited under this kernel",
+            f"* MFMA pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8) = **{c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.1f} %** of the cycles the chip actually ran",
+            f"* LDS: SQ_LDS_BANK_CONFLICT = {c['SQ_LDS_BANK_CONFLICT']:.0f} (conflict-free swizzle), SQ_LDS_IDX_ACTIVE / 256 CUs = "
+            f"{c['SQ_LDS_IDX_ACTIVE'] / 256 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.0f} % of cycles",
+            f"* memory side: FETCH_SIZE {fetch_kb / 1e6:.3f} GB x 2 (gfx950 16-byte-lane correction, MI355X_MICROARCH.md §HBM) = "
+            f"**{2 * fetch_kb / 1e6:.2f} GB**, WRITE_SIZE **{write_kb / 1e6:.2f} GB** per launch; algorithmic bytes (A + B + C once) "
+            f"{algo / 1e9:.2f} GB.  The fetch figure counts every L2 miss at the fabric, Infinity-Cache hits included: an XCD's 32 "
+            "concurrent 256x256 tiles form a 4 x 8 rectangle that needs 12 operand panels per K sweep, 24 sweeps per XCD "
+            "=> ~4.8 GB by construction; the 256 MB Infinity Cache absorbs the re-reads (B = 0.10 GB stays resident), so this is "
+            "~2 TB/s of fabric traffic under an MFMA-bound kernel, not HBM over-fetch.",
+            "", "| counter | per dispatch |", "|---|---|"]
+    out += [f"| {a} | {b:.4g} |" for a, b in sorted(c.items())]
+    a = pmc("attn_sq")
+    out += ["", "## attention kernels, B 8, S 2048, 16 heads, hd 128, causal (`python tools/attn_one.py bwd`)", "",
+            "| kernel | us | clock GHz | MFMA busy % | LDS active % of CU cycles | LDS conflict / active | WAIT_ANY / WAVE_CYCLES |", "|---|---|---|---|---|---|---|"]
+    for k, (c, us) in a.items():
+        if "attn" not in k or "delta" in k:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        out.append(f"| `{k}` | {us:.0f} | {cyc / us / 1e3:.2f} | {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.0f} | "
+                   f"{c['SQ_LDS_IDX_ACTIVE'] / 256 / cyc * 100:.0f} | {c['SQ_LDS_BANK_CONFLICT'] / max(1, c['SQ_LDS_IDX_ACTIVE']):.2f} | "
+                   f"{c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f} |")
+    open(dst + "_pmc.md", "w").write("\n".join(out) + "\n")
+    json.dump({"kernel": "gemm_256_kernel<0>", "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
+               "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md §HBM"},
+              open(dst + "_gemm_traffic.json", "w"), indent=1)
+
+
+stats_md()
+pmc_md()
+os.system(f"cp {src}/kernel_microbench.jsonl {dst}_kernel_microbench.jsonl; grep -h weighted8 {src}/gemm_shapes.json > {dst}_gemm_shapes.json")
+os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
