@@ -44,14 +44,16 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
                           int ldw, int ld_act, int ld_gu, int batch, long long strideA, long long strideW,
                           long long stride_act, long long stride_gu, const int* m_valid, hipStream_t stream);
 
-/* Weight-gradient accumulate with deterministic split-K: C (fp32, M x N) += At (M x K) * Bt (N x K)^T for long K
- * (tokens) and few output tiles (main_grad accumulation of nn.Linear weights; the reference gets this from autograd +
- * DeepSpeed's fp32 gradient accumulation).  workspace: 16-byte aligned device memory, zeroed ONCE by the caller, used
- * by one stream at a time: 16 KiB of tile semaphores (self-resetting) + up to 8 partial [M x N] fp32 images; its size
- * bounds the split (NULL: plain lmod_gemm_bf16_nt with out_f32 + accumulate).  The last split to arrive adds all
- * partials in split order, so the result does not depend on scheduling. */
-int lmod_gemm_wgrad_bf16_nt(const void* At, const void* Bt, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                            void* workspace, long long workspace_bytes, hipStream_t stream);
+/* Weight-gradient accumulate: C (fp32, M x N) += At (M x K) * X, K = tokens (main_grad accumulation of nn.Linear
+ * weights, dW = dY^T X; the reference gets this from autograd + DeepSpeed's fp32 gradient accumulation).
+ * At = dY^T [M x K] (K-contiguous).  X: b_kmajor 0 -> Bt [N x K] (K-contiguous); b_kmajor 1 -> the layer input as
+ * autograd holds it, [K x N] with row stride ldb (read through transposing LDS reads, no transposed copy).
+ * Few-tile outputs use deterministic split-K.  workspace: 16-byte aligned device memory, zeroed ONCE by the caller,
+ * used by one stream at a time: 16 KiB of tile semaphores (self-resetting) + up to 8 partial images of 256 KiB per
+ * 256x256 tile; its size bounds the split (NULL: no split).  The last split to arrive adds all partials in split
+ * order, so the result does not depend on scheduling. */
+int lmod_gemm_wgrad_bf16_nt(const void* At, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int b_kmajor, void* workspace, long long workspace_bytes, hipStream_t stream);
 
 /* Weight-gradient GEMM: C[b] (M x N) (+)= A[b]^T * B[b], A [K x M] (lda), B [K x N] (ldb) — dW = dY^T X on the
  * token-major tensors autograd holds (the implicit grad_output.t() @ input of nn.Linear's backward; reference

@@ -294,9 +294,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 // rows, 32-byte blocks XOR-swizzled by (k&3 | (k>>3&1)<<2)) filled by LDS-DMA; the MFMA operand fragments (8
 // consecutive k for one m per lane) come out of it through ds_read_b64_tr_b16 (hardware transpose read),
 // conflict-free.  Columns are in natural order, so a lane owns 4 groups of 4 contiguous output columns.
+// MODE 3 (the step's wgrad): A = dY^T K-contiguous as in MODE 0, B = X reduction-major as in MODE 2 — only dY needs
+// a transposed copy, and two thirds of the operand fragments keep the full-rate ds_read_b128 path.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
+  constexpr bool AK = (MODE == 2), BK = (MODE == 2 || MODE == 3);      // operand stored reduction-major?
+  constexpr bool SPLIT_OK = (MODE == 0 || MODE == 3);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const int tpb = p.tiles_m * p.tiles_n;
   int id = xcd_remap(blockIdx.x, gridDim.x);
   int bz = id / tpb, split = 0;
-  if (MODE == 0 && p.splitk > 1) {      // split-major: an XCD's contiguous chunk is many tiles of ONE K split (same L2 reuse)
+  if (SPLIT_OK && p.splitk > 1) {      // split-major: an XCD's contiguous chunk is many tiles of ONE K split (same L2 reuse)
     split = bz; bz = 0; id -= split * tpb;
   }
   const int r = id - bz * tpb;
@@ -331,13 +335,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const int row0 = tm * 256, col0 = tn * TN;
   if (row0 >= Mv) return;
   int kbeg = 0;
-  if (MODE == 0 && p.splitk > 1) {      // long-K, few-tile problems (wgrad): the batch index is the K split
+  if (SPLIT_OK && p.splitk > 1) {      // long-K, few-tile problems (wgrad): the batch index is the K split
     kbeg = split * p.kchunk;
     Kv = max(0, min(Kv - kbeg, p.kchunk));      // an empty split still arrives at the semaphore with a zero tile
   }
 
-  const bf16_t* Ab = p.A + (long long)bz * p.sA + (MODE == 2 ? (long long)row0 : (long long)row0 * p.lda) + kbeg;
-  const bf16_t* Bb = p.B + (long long)bz * p.sB + (MODE == 2 ? (long long)col0 : (long long)col0 * p.ldb) + kbeg;
+  const bf16_t* Ab = p.A + (long long)bz * p.sA + (AK ? (long long)row0 + (long long)kbeg * p.lda : (long long)row0 * p.lda + kbeg);
+  const bf16_t* Bb = p.B + (long long)bz * p.sB + (BK ? (long long)col0 + (long long)kbeg * p.ldb : (long long)col0 * p.ldb + kbeg);
   const int rowsA = min(256, Mv - row0), rowsB = min(TN, p.N - col0);
   const int Kv8 = (Kv + 7) & ~7;
   const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
@@ -348,30 +352,28 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   // ---- staging offsets: this wave fills half-tile rows 16*wave + 8*j + (lane>>3), physical chunk lane&7 ----
   const int cchunk = (lane & 7) ^ (lane >> 3);
   uint32_t voA[2][2], voB[2][2];      // [half][j]
-  if constexpr (MODE == 2) {
-    // reduction-major image: this wave fills k rows 8*wave + 4*j + (lane>>4), physical 16-byte chunk lane&15
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int krow = wave * 8 + j * 4 + (lane >> 4), pc = lane & 15;
-        const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
-        const int mp = ((((pc >> 1) ^ key) << 1) | (pc & 1)) * 8;      // logical position 0..127 in the half-tile
-        const int ra = (mp >> 6) * 128 + h * 64 + (mp & 63);           // A: tile row (both wave rows' M-half h)
-        const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
-        voA[h][j] = (ra < rowsA) ? (uint32_t)((krow * p.lda + ra) * 2) : GEMM_OOB;
-        voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
-      }
-  } else {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      // reduction-major image: this wave fills k rows 8*wave + 4*j + (lane>>4), physical 16-byte chunk lane&15
+      const int krow = wave * 8 + j * 4 + (lane >> 4), pc = lane & 15;
+      const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int mp = ((((pc >> 1) ^ key) << 1) | (pc & 1)) * 8;        // logical position 0..127 in the half-tile
+      // K-contiguous image: this wave fills half-tile rows 16*wave + 8*j + (lane>>3), physical chunk lane&7
       const int hr = wave * 16 + j * 8 + (lane >> 3);                 // half-tile row 0..127
-      const int ra = (hr >> 6) * 128 + h * 64 + (hr & 63);             // A: tile row
-      voA[h][j] = (ra < rowsA) ? (uint32_t)((ra * p.lda + cchunk * 8) * 2) : GEMM_OOB;
+      if constexpr (AK) {
+        const int ra = (mp >> 6) * 128 + h * 64 + (mp & 63);           // A: tile row (both wave rows' M-half h)
+        voA[h][j] = (ra < rowsA) ? (uint32_t)((krow * p.lda + ra) * 2) : GEMM_OOB;
+      } else {
+        const int ra = (hr >> 6) * 128 + h * 64 + (hr & 63);           // A: tile row
+        voA[h][j] = (ra < rowsA) ? (uint32_t)((ra * p.lda + cchunk * 8) * 2) : GEMM_OOB;
+      }
       const int wcs = hr >> 5, rl = hr & 31, ntl = rl >> 4, ii = rl & 15;
-      if (MODE == 0) {
+      if constexpr (BK) {
+        const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
+        voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
+      } else if (MODE == 0) {
         const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       } else {       // half h = gate (0) / up (1) rows of the same 128 output columns
@@ -379,7 +381,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((((long long)h * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       }
     }
-  }
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   auto stage = [&](int kind, int t) {
     const int k0 = t * 64;
     char* dst = smem + (t & 1) * (4 * G256_SLOT) + kind * G256_SLOT + wave * 2048;
-    if constexpr (MODE == 2) {
+    const bool kmaj = (kind < 2) ? AK : BK;
+    if (kmaj) {
       // the K advance goes into the (64-bit) base: byte offsets of a token-major operand overflow 32 bits
       const long long adv = (long long)k0 * (kind < 2 ? p.lda : p.ldb);
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((kind < 2 ? Ab : Bb) + adv), 0,
@@ -405,14 +407,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + j * 1024), 16, v, 0, 0, 0);
       }
     } else {
-    const bool dead = (k0 + cchunk * 8 >= Kv);
+      const bool dead = (k0 + cchunk * 8 >= Kv);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
-      if (dead) v = GEMM_OOB;
-      if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
-    }
+      for (int j = 0; j < 2; ++j) {
+        uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
+        if (dead) v = GEMM_OOB;
+        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+      }
     }
   };
 
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     return (bf16x8){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
   };
   auto readA = [&](int t, int mh) {
-    if constexpr (MODE == 2) {
+    if constexpr (AK) {
       const char* sl = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT;
 #pragma unroll
       for (int ml = 0; ml < 4; ++ml) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     }
   };
   auto readB = [&](int t, int nh) {
-    if constexpr (MODE == 2) {
+    if constexpr (BK) {
       const char* sl = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT;
 #pragma unroll
       for (int nl = 0; nl < 2; ++nl) {
@@ -549,12 +551,19 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     }
     return;
   }
-  if constexpr (MODE == 2) {      // natural column order: lane owns columns cw + nt*16 + g*4 + (0..3), nt = 0..3
+  if constexpr (BK) {      // natural column order: lane owns columns cw + nt*16 + (0..3), nt = 0..3
     const int cw = col0 + wc * 64 + g * 4;
     char* Cb2 = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : 2);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const int row = row0 + wr * 128 + mt * 16 + li;
+      if (SPLIT_OK && p.splitk > 1) {      // partial tile -> workspace, lane-linear (reduced below by the last split)
+        float* wp = p.ws + (((long long)split * tpb + id) * 32 + mt * 4) * 2048 + tid * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + nt * 2048), "v"(acc[mt][nt]) : "memory");
+        continue;
+      }
       if (row >= Mv) continue;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -575,8 +584,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         }
       }
     }
-    return;
+    if (!(SPLIT_OK && p.splitk > 1)) return;
   }
+  if constexpr (!BK) {
   const int cb = col0 + wc * 64 + g * 16;
   float bia[16];
 #pragma unroll
@@ -637,7 +647,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       }
     }
   }
-  if (MODE == 0 && p.splitk > 1) {
+  }   // !BK epilogue
+  if (SPLIT_OK && p.splitk > 1) {
     // Deterministic split-K reduction: every split publishes its partial tile, the LAST one to arrive adds all of
     // them in split order (its own included, re-read) plus the old C.  Arrival order never changes the result.
     // The splits of a tile run on different XCDs (private L2s): the partials move with agent-scope (sc1) stores and
@@ -652,11 +663,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     float* Cf = (float*)p.C;
     for (int mt = 0; mt < 8; ++mt) {
       const int row = row0 + wr * 128 + mt * 16 + li;
-      const bool live = (row < Mv) && (cb < p.N);     // N % 16 == 0: a lane's 16 columns are all in or all out
+      // lane-linear partial x of row-tile mt holds 4 contiguous columns starting at colx(x)
+      auto colx = [&](int x) { return BK ? col0 + wc * 64 + (lane >> 4) * 4 + 16 * x : col0 + wc * 64 + (lane >> 4) * 16 + 4 * x; };
       f32x4 o[4];
+      bool live[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
-        o[x] = live ? *(f32x4*)(Cf + (long long)row * p.ldc + cb + 4 * x) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int x = 0; x < 4; ++x) {
+        live[x] = (row < Mv) && (colx(x) < p.N);      // N % 4 == 0: a group of 4 columns is all in or all out
+        o[x] = live[x] ? *(f32x4*)(Cf + (long long)row * p.ldc + colx(x)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
       for (int s0 = 0; s0 < p.splitk; s0 += 4) {      // up to 16 agent-scope loads in flight
         f32x4 part[4][4];
 #pragma unroll
@@ -677,10 +692,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
             }
           }
       }
-      if (live) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) *(f32x4*)(Cf + (long long)row * p.ldc + cb + 4 * x) = o[x];
-      }
+      for (int x = 0; x < 4; ++x)
+        if (live[x]) *(f32x4*)(Cf + (long long)row * p.ldc + colx(x)) = o[x];
     }
     if (tid == 0) __hip_atomic_store(p.counters + id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
   }
@@ -812,7 +826,8 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
   return lmod_launch_status();
 }
 
-// Weight-gradient accumulate C (fp32, M x N) += At (M x K) * Bt (N x K)^T for long K (tokens) and few output tiles:
+// Weight-gradient accumulate C (fp32, M x N) += At (M x K) * X for long K (tokens); X is either Bt [N x K] (K-contiguous,
+// b_kmajor 0) or the activation as autograd holds it, [K x N] (b_kmajor 1: no transposed copy of X).  Few output tiles:
 // deterministic split-K.  `workspace` (16-byte aligned, zeroed ONCE by the caller, used by one stream at a time) holds
 // 16 KiB of tile semaphores followed by up to 8 partial images (256 KiB per 256x256 tile); its size bounds the split.  With a NULL /
 // small workspace, or when splitting does not pay, this is lmod_gemm_bf16_nt(out_f32, accumulate).
@@ -834,22 +849,26 @@ static int wgrad_pick_split(int M, int N, int K, int max_s) {
   return best_s;
 }
 
-int lmod_gemm_wgrad_bf16_nt(const void* At, const void* Bt, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                            void* workspace, long long workspace_bytes, hipStream_t stream) {
-  if (!At || !Bt || !C || M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
-  // the workspace bounds the split: WGRAD_MAX_TILES semaphores (16 KiB) + s partial [M, N] fp32 images
+int lmod_gemm_wgrad_bf16_nt(const void* At, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int b_kmajor, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  if (!At || !B || !C || M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0) return LMOD_OK;
+  // the workspace bounds the split: WGRAD_MAX_TILES semaphores (16 KiB) + s partial images of 256 KiB per tile
   long long cap = 0;
-  if (workspace && !((uintptr_t)workspace & 15) && M > 0 && N > 0)
+  if (workspace && !((uintptr_t)workspace & 15))
     cap = (workspace_bytes - (long long)WGRAD_MAX_TILES * 4) / ((long long)((M + 255) / 256) * ((N + 255) / 256) * 262144);
   int s = wgrad_pick_split(M, N, K, (int)(cap < 1 ? 1 : (cap > 8 ? 8 : cap)));
-  if (s > 1 && (((uintptr_t)C & 15) || (ldc & 3) ||
-                (long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL || (long long)255 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL))
-    s = 1;
-  if (s == 1) return lmod_gemm_bf16_nt(At, Bt, C, nullptr, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, nullptr, nullptr, 0, 1, 1, stream);
-  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return LMOD_EINVAL;
-  if (((uintptr_t)At & 15) || ((uintptr_t)Bt & 15)) return LMOD_EINVAL;
+  if (s > 1 && (((uintptr_t)C & 15) || (ldc & 3))) s = 1;
+  if (!b_kmajor && (s == 1 || (long long)255 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL ||
+                    (long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL))
+    return lmod_gemm_bf16_nt(At, B, C, nullptr, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, nullptr, nullptr, 0, 1, 1, stream);
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldc < N || ((uintptr_t)At & 15) || ((uintptr_t)B & 15)) return LMOD_EINVAL;
+  if (b_kmajor) {        // B = X as stored: [K, N], N contiguous
+    if ((N & 7) || ldb < N || ((uintptr_t)C & 15) || (ldc & 3)) return LMOD_EINVAL;
+    if ((long long)64 * ldb * 2 >= 0x7fffffffLL || (long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  } else if (ldb < K) return LMOD_EINVAL;
   GemmP p;
-  p.A = (const bf16_t*)At; p.B = (const bf16_t*)Bt; p.C = C; p.bias = nullptr;
+  p.A = (const bf16_t*)At; p.B = (const bf16_t*)B; p.C = C; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.batch = 1; p.sA = 0; p.sB = 0; p.sC = 0;
   p.m_valid = nullptr; p.k_valid = nullptr;
@@ -858,9 +877,14 @@ int lmod_gemm_wgrad_bf16_nt(const void* At, const void* Bt, float* C, int M, int
   p.splitk = s; p.kchunk = ((K + s - 1) / s + 63) / 64 * 64;
   p.counters = (int*)workspace; p.ws = (float*)((char*)workspace + (long long)WGRAD_MAX_TILES * 4);
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-  (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
   const long long nwg = (long long)p.tiles_m * p.tiles_n * s;
-  hipLaunchKernelGGL(gemm_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  if (b_kmajor) {
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    hipLaunchKernelGGL(gemm_256_kernel<3>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    hipLaunchKernelGGL(gemm_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  }
   return lmod_launch_status();
 }
 

@@ -67,16 +67,20 @@ _WGRAD_WS = {}
 WGRAD_WS_BYTES = 512 << 20
 
 
-def gemm_wgrad(at, bt, out):
-    """out (fp32 [M, N]) += at[M, K] @ bt[N, K]^T with deterministic split-K when the output has too few tiles to fill
+def gemm_wgrad(at, b, out, b_kmajor=False):
+    """out (fp32 [M, N]) += at[M, K] @ X with X = b[N, K]^T (b_kmajor False) or b[K, N] as autograd holds the layer
+    input (b_kmajor True: no transposed copy of it).  Deterministic split-K when the output has too few tiles to fill
     the GPU (K = tokens).  One zero-initialised workspace per device, reused by every call on the compute stream."""
     key = at.device.index
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = _WGRAD_WS[key] = torch.zeros(WGRAD_WS_BYTES, device=at.device, dtype=torch.uint8)
     M, Kd = at.shape
-    call("lmod_gemm_wgrad_bf16_nt", ptr(at), ptr(bt), ptr(out), M, bt.shape[0], Kd, at.stride(0), bt.stride(0),
-         out.stride(0), ptr(ws), ws.numel())
+    if b_kmajor:
+        Kd = min(Kd, b.shape[0])              # at is zero-padded to a multiple of 8 tokens by the transpose
+    N = b.shape[1] if b_kmajor else b.shape[0]
+    call("lmod_gemm_wgrad_bf16_nt", ptr(at), ptr(b), ptr(out), M, N, Kd, at.stride(0), b.stride(0),
+         out.stride(0), int(b_kmajor), ptr(ws), ws.numel())
     return out
 
 

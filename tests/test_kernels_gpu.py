@@ -189,6 +189,17 @@ def test_gemm_wgrad_splitk_deterministic(M, N, Kd):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split-K must not depend on arrival order"
     K.gemm_wgrad(at, bt, outs[0])                      # accumulates on top
     close(outs[0], 2 * ref + 0.5, "wgrad accumulate twice", rtol=1e-4, afrac=1e-5)
+    # X reduction-major as autograd holds it ([K, N], a column sub-view): same answer, same determinism
+    x_full = torch.zeros(Kd, N + 8, device=DEV, dtype=BF)
+    x_full[:, :N] = bt.t()
+    x = x_full[:, :N]
+    outs = []
+    for _ in range(2):
+        g = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+        K.gemm_wgrad(at, x, g, b_kmajor=True)
+        outs.append(g)
+    close(outs[0], ref + 0.5, f"wgrad k-major X {M}x{N}x{Kd}", rtol=1e-4, afrac=1e-5)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_transpose():

@@ -1,4 +1,4 @@
-"""wgrad forms at the student's shapes: transposes + NT GEMM (plain / deterministic split-K) vs the TN kernel."""
+"""wgrad forms at the student's shapes: NT (both operands transposed copies) vs X read reduction-major (MODE 3) vs TN."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llava-mod_amd"))
@@ -16,8 +16,8 @@ for tag, M, N in [("gate+up", 11008, 2048), ("qkv", 6144, 2048), ("down", 2048, 
     g = torch.zeros(M, N, device="cuda", dtype=torch.float32)
     fl = 2.0 * T * M * N
     dyt, xt = K.transpose(dy), K.transpose(x)
-    res = {"transposes": t(lambda: (K.transpose(dy), K.transpose(x))),
-           "nt": t(lambda: K.gemm_nt(dyt, xt, out=g, out_f32=True, accumulate=True)),
-           "nt_splitk": t(lambda: K.gemm_wgrad(dyt, xt, g)),
+    res = {"T(dy)": t(lambda: K.transpose(dy)), "T(x)": t(lambda: K.transpose(x)),
+           "nt": t(lambda: K.gemm_wgrad(dyt, xt, g)),
+           "x_kmajor": t(lambda: K.gemm_wgrad(dyt, x, g, b_kmajor=True)),
            "tn": t(lambda: K.gemm_tn(dy, x, out=g, accumulate=True))}
-    print(tag, {k: f"{v:.3f}ms {fl / v / 1e9:.0f}TF" for k, v in res.items()}, flush=True)
+    print(tag, {k: f"{v:.3f}ms" + (f" {fl / v / 1e9:.0f}TF" if not k.startswith("T(") else "") for k, v in res.items()}, flush=True)
