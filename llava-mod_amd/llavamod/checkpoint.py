@@ -1,0 +1,115 @@
+"""Checkpoint I/O in the reference's key layout.
+
+The reference saves through HF `save_pretrained` (sharded safetensors + `model.safetensors.index.json`) and writes the
+trainable projector separately as `mm_projector.bin` (`train/align_train.py:623-631`, read back by
+`llava_arch.py:122-128`).  The module tree here already carries the reference's parameter names
+(`model.layers.N.mlp.deepspeed_moe.gate.wg.weight`, `…deepspeed_experts.E.{gate,up,down}_proj.weight`,
+`model.mm_projector.image_spatial_proj.{0,2}.*`, `model.image_tower.image_tower.vision_model.*`), so this is plain
+name -> tensor I/O plus the two key dialects a real checkpoint may use.
+"""
+import json
+import os
+import re
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import save_file
+
+INDEX = "model.safetensors.index.json"
+
+
+def _normalise(key):
+    """Accept HF-transformers-5.x CLIP keys (no `vision_model.` level) and DeepSpeed's `module.` prefix."""
+    if key.startswith("module."):
+        key = key[len("module."):]
+    m = re.match(r"(model\.image_tower\.image_tower\.)(?!vision_model\.)(.*)", key)
+    if m:
+        key = m.group(1) + "vision_model." + m.group(2)
+    return key
+
+
+def save_checkpoint(model, out_dir, max_shard_bytes=5 << 30, projector_file=True):
+    """Write `model-XXXXX-of-YYYYY.safetensors` + index (HF layout) and, like the reference's trainer, the projector
+    weights alone as `mm_projector.bin`.  Returns the list of files written."""
+    os.makedirs(out_dir, exist_ok=True)
+    sd = {k: v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
+    shards, cur, size = [], {}, 0
+    for k, v in sd.items():
+        n = v.numel() * v.element_size()
+        if cur and size + n > max_shard_bytes:
+            shards.append(cur); cur, size = {}, 0
+        cur[k] = v; size += n
+    if cur:
+        shards.append(cur)
+    files, weight_map = [], {}
+    for i, sh in enumerate(shards):
+        name = "model.safetensors" if len(shards) == 1 else f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+        save_file(sh, os.path.join(out_dir, name), metadata={"format": "pt"})
+        files.append(name)
+        weight_map.update({k: name for k in sh})
+    if len(shards) > 1:
+        total = sum(v.numel() * v.element_size() for v in sd.values())
+        json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, open(os.path.join(out_dir, INDEX), "w"), indent=1)
+        files.append(INDEX)
+    if projector_file:
+        proj = {k: v for k, v in sd.items() if "mm_projector" in k}
+        if proj:
+            torch.save(proj, os.path.join(out_dir, "mm_projector.bin"))
+            files.append("mm_projector.bin")
+    return files
+
+
+def _read(path):
+    if path.endswith(".safetensors"):
+        with safe_open(path, framework="pt", device="cpu") as f:
+            return {k: f.get_tensor(k) for k in f.keys()}
+    return torch.load(path, map_location="cpu")
+
+
+def read_state(path):
+    """A directory (HF shards / single file / *.bin), a .safetensors file or a torch-pickled state dict -> {name: tensor}."""
+    if os.path.isdir(path):
+        idx = os.path.join(path, INDEX)
+        if os.path.exists(idx):
+            names = sorted(set(json.load(open(idx))["weight_map"].values()))
+        else:
+            names = sorted(n for n in os.listdir(path) if n.endswith(".safetensors")) or \
+                    sorted(n for n in os.listdir(path) if re.fullmatch(r"pytorch_model.*\.bin", n))
+        if not names:
+            raise FileNotFoundError(f"no model weights under {path}")
+        out = {}
+        for n in names:
+            out.update(_read(os.path.join(path, n)))
+        return out
+    return _read(path)
+
+
+def load_checkpoint(model, path, strict=True):
+    """Copy tensors into `model` by (normalised) name, casting to each parameter's dtype/device.  Checkpoints saved
+    BEFORE up-cycling (dense `mlp.{gate,up,down}_proj`) load into an up-cycled model the way the reference's
+    `initialize_moe_modules` does: every expert receives the dense FFN (`llava_qwen2_moe.py:547-556`).
+    Returns (missing, unexpected)."""
+    src = {_normalise(k): v for k, v in read_state(path).items()}
+    own = model.state_dict()
+    used, missing = set(), []
+    with torch.no_grad():
+        for k, t in own.items():
+            v = src.get(k)
+            if v is None:
+                m = re.match(r"(.*\.mlp\.)deepspeed_moe\.experts\.deepspeed_experts\.\d+\.(.*)", k)
+                if m and (m.group(1) + m.group(2)) in src:
+                    v = src[m.group(1) + m.group(2)]
+                    used.add(m.group(1) + m.group(2))
+            else:
+                used.add(k)
+            if v is None:
+                missing.append(k)
+                continue
+            if tuple(v.shape) != tuple(t.shape):
+                raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model shape {tuple(t.shape)}")
+            t.copy_(v.to(device=t.device, dtype=t.dtype))
+    unexpected = sorted(set(src) - used)
+    if strict and (missing or unexpected):
+        raise KeyError(f"missing {missing[:5]}{'...' if len(missing) > 5 else ''}, "
+                       f"unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+    return missing, unexpected
