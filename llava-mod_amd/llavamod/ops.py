@@ -151,7 +151,9 @@ def linear_dgrad(dy, fw):
 
 
 def linear_wgrad(dy, x, fw):
-    """main_grad += dy^T @ x ; bias main_grad += colsum(dy)."""
+    """main_grad += dy^T @ x ; bias main_grad += colsum(dy).
+    (Measured and rejected: running the transposes, or the whole weight gradient, on a side stream.  Two GEMMs sharing
+    the chip run slower than back to back (-2 %), and the transposes alone did not hide under the dgrad GEMM.)"""
     dyt = K.transpose(dy)                     # [N, Tpad]
     xt = K.transpose(x)                       # [K, Tpad]
     K.gemm_wgrad(dyt, xt, fw.grad_buffer())
@@ -397,8 +399,8 @@ class MoEBlock(torch.autograd.Function):
         K.gemm_nt(dy.view(E, C, H), sp.down.transposed(), out=dact, m_valid=rows)
         gu2 = gu.view(E * C, 2 * I)
         if sp.down.requires_grad:
-            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act), out=sp.down.grad_buffer(),
-                      out_f32=True, accumulate=True, k_valid=rows)
+            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act), out=sp.down.grad_buffer(), out_f32=True,
+                      accumulate=True, k_valid=rows)
             sp.down.grad_done()
         dgu = torch.empty_like(gu)
         dgu2 = dgu.view(E * C, 2 * I)

@@ -46,16 +46,44 @@ class AlignTrainer:
     def _dev(self):
         return next(self.ref_model.parameters()).device
 
-    def compute_loss(self, model, inputs, return_outputs=False):
-        assert self.ref_model is not None, "ref model can not be none!"
-        batch = dict(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
-                     labels=inputs.get("labels"), images=inputs.get("images"))
-        with torch.no_grad():                                  # teacher forward (:556-560)
-            # the teacher only feeds the loss rows: its last layer and lm_head run on those rows alone
+    # ---- teacher pass --------------------------------------------------------------------------------
+    def _teacher_pass(self, batch):
+        """Frozen teacher forward (:556-560) down to what the loss consumes: the loss plan and the teacher's logits
+        on the loss rows ([R, Vt] bf16) — its last layer and lm_head run on those rows alone."""
+        with torch.no_grad():
             t_rows, _, t_info = self.ref_model.forward_hidden(**batch, plan_fn=lambda info: self._plan(info, self._dev()))
-            teacher_plan = t_info.plan
-            t_logits = ops.linear_fwd(t_rows, self.ref_model.head())          # [R, Vt] bf16, loss rows only
-            del t_rows
+            t_logits = ops.linear_fwd(t_rows, self.ref_model.head())
+        return SimpleNamespace(plan=t_info.plan, logits=t_logits, event=None)
+
+    @staticmethod
+    def _batch_of(inputs):
+        return dict(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
+                    labels=inputs.get("labels"), images=inputs.get("images"))
+
+    def prefetch_teacher(self, inputs):
+        """Run the teacher pass for a FUTURE batch on a side stream and return a handle for
+        `compute_loss(..., teacher=handle)`.  The teacher is frozen, so its forward for batch i+1 does not depend on
+        the student's update i: issued before the student's step, its HBM-bound row kernels execute under the
+        student's MFMA-bound GEMMs and vice versa (same work per step, shorter wall clock)."""
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = torch.cuda.Stream(device=self._dev())
+        with torch.cuda.stream(self._tstream):
+            h = self._teacher_pass(self._batch_of(inputs))
+            h.event = torch.cuda.Event()
+            h.event.record(self._tstream)
+        return h
+
+    def compute_loss(self, model, inputs, return_outputs=False, teacher=None):
+        assert self.ref_model is not None, "ref model can not be none!"
+        batch = self._batch_of(inputs)
+        if teacher is None:
+            teacher = self._teacher_pass(batch)
+        elif teacher.event is not None:                       # produced on the side stream: order and pin its memory
+            cur = torch.cuda.current_stream()
+            cur.wait_event(teacher.event)
+            for t in [teacher.logits] + [v for v in vars(teacher.plan).values() if torch.is_tensor(v)]:
+                t.record_stream(cur)
+        teacher_plan, t_logits = teacher.plan, teacher.logits
         # same inputs => same spliced labels => same loss rows: the student's last (dense) layer is trimmed the same way
         s_hidden, moe_list, s_info = model.forward_hidden(**batch, plan_fn=lambda info: copy.copy(teacher_plan))
         plan = s_info.plan
@@ -78,8 +106,8 @@ class AlignTrainer:
         self.store_metrics({k: v.detach() for k, v in outputs.items()}, train_eval="train")
         return (losses.mean(), outputs) if return_outputs else losses.mean()
 
-    def training_step(self, model, inputs):
-        loss = self.compute_loss(model, inputs)
+    def training_step(self, model, inputs, teacher=None):
+        loss = self.compute_loss(model, inputs, teacher=teacher)
         loss.backward()
         return loss.detach()
 

@@ -313,3 +313,30 @@ def test_teacher_row_trimmed_forward_is_exact():
         (y.float() * w).sum().backward()
         grads.append(e.grad.float())
     assert U.relerr(grads[1], grads[0]) < 2e-2, U.relerr(grads[1], grads[0])
+
+
+def test_prefetched_teacher_equals_inline():
+    """The side-stream teacher pass (engine pipelining) feeds compute_loss the same plan and logits as the inline one."""
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=512)
+    b0, b1 = _batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")
+    h0, h1 = tr.prefetch_teacher(b0), tr.prefetch_teacher(b1)          # two passes in flight on the side stream
+    for batch, h in ((b0, h0), (b1, h1)):
+        grads = []
+        for teacher_arg in (h, None):
+            for p in student.parameters():
+                if getattr(p, "main_grad", None) is not None:
+                    p.main_grad.zero_()
+            loss = tr.compute_loss(student, batch, teacher=teacher_arg)
+            loss.backward()
+            grads.append((float(loss), {n: p.main_grad.clone() for n, p in student.named_parameters()
+                                        if getattr(p, "main_grad", None) is not None}))
+        assert grads[0][0] == grads[1][0]
+        assert all(torch.equal(grads[0][1][n], grads[1][1][n]) for n in grads[0][1])
