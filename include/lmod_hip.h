@@ -44,6 +44,15 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
                           int ldw, int ld_act, int ld_gu, int batch, long long strideA, long long strideW,
                           long long stride_act, long long stride_gu, const int* m_valid, hipStream_t stream);
 
+/* Down-projection dgrad with the SwiGLU backward in its epilogue: dact = A (M x K) * Bt^T (Bt = W_down^T, N x K), then
+ * dgu = [dact * up * silu'(gate) | dact * silu(gate)] (M x 2N) from the saved pre-activations gu = [gate | up];
+ * d(act) is never written (autograd of `down_proj(act_fn(gate_proj(x)) * up_proj(x))`, qwen2/modeling_qwen2.py:186-187).
+ * dgu may alias gu.  Grouped use as lmod_gemm_bf16_nt; rows m_valid..roundup8(m_valid)-1 of dgu are zeroed.
+ * Requires K % 8 == 0, N % 16 == 0, 16-byte aligned pointers, leading dims % 8 == 0. */
+int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, void* dgu, int M, int N, int K, int lda,
+                              int ldb, int ld_gu, int ld_dgu, int batch, long long strideA, long long strideB,
+                              long long stride_gu, long long stride_dgu, const int* m_valid, hipStream_t stream);
+
 /* Weight-gradient accumulate: C (fp32, M x N) += At (M x K) * X, K = tokens (main_grad accumulation of nn.Linear
  * weights, dW = dY^T X; the reference gets this from autograd + DeepSpeed's fp32 gradient accumulation).
  * At = dY^T [M x K] (K-contiguous).  X: b_kmajor 0 -> Bt [N x K] (K-contiguous); b_kmajor 1 -> the layer input as

@@ -51,6 +51,24 @@ __device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
   return o;
 }
 
+// SwiGLU backward on 8 (dact, gate, up) triples packed as bf16 pairs — the arithmetic of swiglu_bwd_kernel (rowops.hip).
+__device__ __forceinline__ void swiglu_bwd8(const float (&d)[8], const u32x4 g, const u32x4 u, u32x4& og, u32x4& ou) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gg[2] = {bflo(g[k]), bfhi(g[k])}, uu[2] = {bflo(u[k]), bfhi(u[k])};
+    float rg[2], ru[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float dd = bfround(d[2 * k + e]);                 // the standalone path rounds dact to bf16 in HBM
+      const float sg = 1.f / (1.f + __expf(-gg[e]));
+      rg[e] = dd * uu[e] * (sg * (1.f + gg[e] * (1.f - sg)));
+      ru[e] = dd * (gg[e] * sg);
+    }
+    og[k] = pack2bf(rg[0], rg[1]);
+    ou[k] = pack2bf(ru[0], ru[1]);
+  }
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
   if (act == 2) return v / (1.f + __expf(-1.702f * v));
@@ -603,6 +621,29 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int row = row0 + wr * 128 + mt * 16 + li;
+    if (MODE == 0 && p.act == 3) {
+      // fused SwiGLU backward (lmod_gemm_swiglu_bwd_bf16): the accumulators are d(act); with the saved [gate | up]
+      // pre-activations (C2) the epilogue writes [dgate | dup] — d(act) never goes to HBM.  N % 16 == 0 (host-checked).
+      if (cb >= p.N || row >= min((Mv + 7) & ~7, p.M)) continue;
+      bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
+      if (row >= Mv) {           // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
+        continue;
+      }
+      const bf16_t* gp = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + (long long)row * p.ldc2 + cb;
+#pragma unroll
+      for (int hx = 0; hx < 2; ++hx) {
+        float d8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d8[e] = acc[mt][hx * 2 + (e >> 2)][e & 3];
+        u32x4 og, ou;
+        swiglu_bwd8(d8, *(const u32x4*)(gp + hx * 8), *(const u32x4*)(gp + p.N + hx * 8), og, ou);
+        *(u32x4*)(op + hx * 8) = og;
+        *(u32x4*)(op + p.N + hx * 8) = ou;
+      }
+      continue;
+    }
     if (row >= Mv) continue;
     float v[16];
 #pragma unroll
@@ -823,6 +864,35 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
   const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   hipLaunchKernelGGL(gemm_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  return lmod_launch_status();
+}
+
+// dgu[b] (M x 2N) = SwiGLU'(gu[b]) applied to dact = A[b] (M x K) * Bt[b]^T (N x K): the down-projection dgrad with the
+// SwiGLU backward in its epilogue.  gu = [gate | up] pre-activations saved by lmod_gemm_swiglu_bf16, dgu = [dgate | dup]
+// (may alias gu).  Grouped use / m_valid as lmod_gemm_bf16_nt; rows m_valid..roundup8(m_valid)-1 of dgu are zeroed.
+int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, void* dgu, int M, int N, int K, int lda,
+                              int ldb, int ld_gu, int ld_dgu, int batch, long long strideA, long long strideB,
+                              long long stride_gu, long long stride_dgu, const int* m_valid, hipStream_t stream) {
+  if (!A || !Bt || !gu || !dgu || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if ((K & 7) || (N & 15) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ld_gu < 2 * N || ld_dgu < 2 * N ||
+      (ld_gu & 7) || (ld_dgu & 7)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) || ((uintptr_t)gu & 15) || ((uintptr_t)dgu & 15) || (stride_gu & 7) ||
+      (stride_dgu & 7)) return LMOD_EINVAL;
+  if ((long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL || (long long)255 * ldb * 2 + (long long)K * 2 >= 0x7fffffffLL)
+    return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)Bt; p.C = dgu; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ld_dgu;
+  p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = stride_dgu;
+  p.m_valid = m_valid; p.k_valid = nullptr;
+  p.act = 3; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
+  p.C2 = (void*)gu; p.ldc2 = ld_gu; p.sC2 = stride_gu; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
+  (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  hipLaunchKernelGGL(gemm_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   return lmod_launch_status();
 }
 

@@ -16,6 +16,7 @@ _P, _I, _Q, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_floa
 SIGNATURES = {
     "lmod_gemm_bf16_nt": "pppp" + "iiiiii" + "iqqq" + "pp" + "iii" + "p",
     "lmod_gemm_swiglu_bf16": "pppp" + "iiiiiii" + "iqqqq" + "p" + "p",
+    "lmod_gemm_swiglu_bwd_bf16": "pppp" + "iiiiiii" + "iqqqq" + "p" + "p",
     "lmod_gemm_wgrad_bf16_nt": "ppp" + "iiiiii" + "i" + "pq" + "p",
     "lmod_gemm_bf16_tn": "ppp" + "iiiiii" + "iqqq" + "p" + "ii" + "p",
     "lmod_transpose_bf16": "pp" + "iiii" + "iqq" + "p",

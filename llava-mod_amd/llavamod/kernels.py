@@ -63,6 +63,21 @@ def gemm_swiglu(x, w_gu, act=None, gu=None, want_gu=False, m_valid=None):
     return act, gu
 
 
+def gemm_swiglu_bwd(dy, wt_down, gu, out=None, m_valid=None, K=None):
+    """dgu[.., M, 2I] = SwiGLU backward of dact = dy[.., M, H] @ wt_down[.., I, Hpad]^T against the saved gu = [gate | up]:
+    the down-projection dgrad GEMM with swiglu_bwd in its epilogue.  out may be gu itself (in place)."""
+    M, Kd = dy.shape[-2], (K if K is not None else dy.shape[-1])
+    I = wt_down.shape[-2]
+    batch = dy.shape[0] if dy.dim() == 3 else 1
+    if out is None:
+        out = torch.empty_like(gu)
+    call("lmod_gemm_swiglu_bwd_bf16", ptr(dy), ptr(wt_down), ptr(gu), ptr(out), M, I, Kd, dy.stride(-2), wt_down.stride(-2),
+         gu.stride(-2), out.stride(-2), batch, dy.stride(0) if dy.dim() == 3 else 0,
+         wt_down.stride(0) if wt_down.dim() == 3 else 0, gu.stride(0) if gu.dim() == 3 else 0,
+         out.stride(0) if out.dim() == 3 else 0, ptr(m_valid))
+    return out
+
+
 _WGRAD_WS = {}
 WGRAD_WS_BYTES = 512 << 20
 

@@ -275,11 +275,14 @@ class MLPBlock(torch.autograd.Function):
         x, gu, act = ctx.saved_tensors
         I = sp.gu.w.shape[0] // 2
         dout = dout.contiguous()
-        dact = linear_dgrad(dout, sp.down)
         if sp.down.requires_grad:
             linear_wgrad(dout, act, sp.down)
-        dgu = torch.empty_like(gu)
-        K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+        if I % 16 == 0:      # down-projection dgrad with the SwiGLU backward in its epilogue: d(act) is never written
+            dgu = K.gemm_swiglu_bwd(dout, sp.down.transposed(), gu, K=sp.down.w.shape[0])
+        else:
+            dact = linear_dgrad(dout, sp.down)
+            dgu = torch.empty_like(gu)
+            K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         dx = linear_dgrad(dgu, sp.gu)
         if sp.gu.requires_grad:
             linear_wgrad(dgu, x, sp.gu)
@@ -395,16 +398,19 @@ class MoEBlock(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros_like(x)
         dy, dw1, dw2 = K.moe_combine_bwd(dout.contiguous(), y.view(E * C, H), st, H)   # dy: zero rows on empty slots
-        dact = torch.empty((E, C, I), device=x.device, dtype=BF16)
-        K.gemm_nt(dy.view(E, C, H), sp.down.transposed(), out=dact, m_valid=rows)
-        gu2 = gu.view(E * C, 2 * I)
         if sp.down.requires_grad:
             K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act), out=sp.down.grad_buffer(), out_f32=True,
                       accumulate=True, k_valid=rows)
             sp.down.grad_done()
-        dgu = torch.empty_like(gu)
-        dgu2 = dgu.view(E * C, 2 * I)
-        K.swiglu_bwd(dact.view(E * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rows)
+        if I % 16 == 0:      # grouped down dgrad + SwiGLU backward in one launch (dead rows: zeroed up to the next 8)
+            dgu = K.gemm_swiglu_bwd(dy.view(E, C, H), sp.down.transposed(), gu, m_valid=rows, K=H)
+        else:
+            dact = torch.empty((E, C, I), device=x.device, dtype=BF16)
+            K.gemm_nt(dy.view(E, C, H), sp.down.transposed(), out=dact, m_valid=rows)
+            gu2 = gu.view(E * C, 2 * I)
+            dgu = torch.empty_like(gu)
+            dgu2 = dgu.view(E * C, 2 * I)
+            K.swiglu_bwd(dact.view(E * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rows)
         d_in = torch.empty((E, C, H), device=x.device, dtype=BF16)
         K.gemm_nt(dgu, sp.gu.transposed(), out=d_in, m_valid=rows)
         if sp.gu.requires_grad:

@@ -110,6 +110,33 @@ def test_gemm_fused_swiglu_grouped():
         assert n8 == C or (act[e, n8:] == 7.0).all(), "rows past the zeroed chunk must not be written"
 
 
+def test_gemm_fused_swiglu_backward():
+    # down-projection dgrad with swiglu_bwd in the epilogue == GEMM + swiglu_bwd kernel, bit for bit; grouped + dead rows
+    M, H, I = 300, 136, 272
+    dy, wd, gu = rnd(M, H, seed=60), rnd(H, I, seed=61), rnd(M, 2 * I, seed=62)
+    wt = K.transpose(wd)                                  # [I, Hpad]
+    dact = K.gemm_nt(dy, wt, M=M, N=I, K=H, lda=H, ldb=wt.stride(0))
+    dg, du = K.swiglu_bwd(dact, gu[:, :I], gu[:, I:])
+    dgu = K.gemm_swiglu_bwd(dy, wt, gu, K=H)
+    assert torch.equal(dgu[:, :I], dg) and torch.equal(dgu[:, I:], du)
+    inplace = gu.clone()
+    K.gemm_swiglu_bwd(dy, wt, inplace, out=inplace, K=H)
+    assert torch.equal(inplace, dgu)
+    E, C = 3, 200
+    dyg, wdg, gug = rnd(E, C, H, seed=63), rnd(E, H, I, seed=64), rnd(E, C, 2 * I, seed=65)
+    wtg = K.transpose(wdg)
+    mv = torch.tensor([200, 0, 77], device=DEV, dtype=torch.int32)
+    out = torch.full((E, C, 2 * I), 7.0, device=DEV, dtype=BF)
+    K.gemm_swiglu_bwd(dyg, wtg, gug, out=out, m_valid=mv, K=H)
+    for e in range(E):
+        n = int(mv[e]); n8 = min((n + 7) // 8 * 8, C)
+        if n:
+            ref = K.gemm_swiglu_bwd(dyg[e, :n].contiguous(), wtg[e], gug[e, :n].contiguous(), K=H)
+            assert torch.equal(out[e, :n], ref), f"expert {e}"
+        assert n8 == n or out[e, n:n8].abs().max().item() == 0
+        assert n8 == C or (out[e, n8:] == 7.0).all()
+
+
 def test_gemm_strided_output_and_subview():
     # write into a column slice of a wider buffer (QKV / gate-up fusion pattern)
     M, N, K_ = 130, 96, 128

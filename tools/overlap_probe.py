@@ -33,3 +33,17 @@ def interleaved_overlap():
     torch.cuda.current_stream().wait_stream(side)
 print("gemms only", wall(gemms), "rows only", wall(rows), "serial", wall(both_serial), "two streams", wall(both_overlap),
       "two streams interleaved", wall(interleaved_overlap))
+
+def event_chained():
+    # row kernels become ready exactly when a GEMM finishes and the next GEMM starts (the AdamW-behind-wgrad pattern)
+    main = torch.cuda.current_stream()
+    for _ in range(8):
+        K.gemm_nt(a, b, out=o)
+        ev = torch.cuda.Event(); ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            K.transpose(x, out=xt); K.rmsnorm_fwd(h, w, 1e-6)
+    K.gemm_nt(a, b, out=o)
+    main.wait_stream(side)
+def nine_gemms(): gemms(9)
+print("9 gemms", wall(nine_gemms), "9 gemms + event-chained rows", wall(event_chained))
