@@ -64,6 +64,23 @@ def test_gemm_random_shapes(M, N, K_):
     close(c, a.float() @ b.float().t(), f"gemm {M}x{N}x{K_}")
 
 
+def test_gemm_big_tile_path_all_epilogues():
+    # large enough for the 256x256 four-wave kernel (>= 160 tiles), ragged edges in M, N and K
+    M, N, K_ = 4000, 2568, 200
+    a, b, bias = rnd(M, K_, seed=70), rnd(N, K_, seed=71), rnd(N, seed=72)
+    ref = a.float() @ b.float().t()
+    close(K_gemm(a, b), ref, "big gemm")
+    pre = (ref + bias.float()).to(BF).float()
+    close(K_gemm(a, b, bias=bias, act=1), F.gelu(pre), "big gemm+bias+gelu")
+    close(K_gemm(a, b, out_f32=True), ref, "big gemm f32", rtol=1e-4, afrac=1e-5)
+    acc = torch.full((M, N), -1.5, device=DEV, dtype=torch.float32)
+    K_gemm(a, b, out=acc, out_f32=True, accumulate=True)
+    close(acc, ref - 1.5, "big gemm f32 accumulate", rtol=1e-4, afrac=1e-5)
+    eye = torch.eye(M, K_, device=DEV, dtype=BF)                      # layout check: C[m, n] = B[n, m] for m < K
+    got = K_gemm(eye, b)
+    assert torch.equal(got[:K_].float(), b.float().t()) and got[K_:].abs().max().item() == 0
+
+
 def test_gemm_bias_act_f32_accumulate():
     M, N, K_ = 200, 264, 320
     a, b, bias = rnd(M, K_, seed=3), rnd(N, K_, seed=4), rnd(N, seed=5)
