@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=16)
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-towers", action="store_true", help="different random CLIP towers: both are run (no feature sharing)")
     ap.add_argument("--no-teacher-prefetch", action="store_true", help="run the teacher forward inline (A/B of the pipelining)")
     ap.add_argument("--ep", type=int, default=1, help="expert-parallel group size (config 5: --experts 8 --ep 8)")
     ap.add_argument("--stage", default="mimic", choices=["mimic", "dpo"],
@@ -163,6 +164,10 @@ def main():
     for p in student.get_model().mm_projector.parameters():
         p.requires_grad = True                                # initialize_vision_modules (llava_arch.py:115-120)
     teacher = LlavaQwen2ForCausalLM(teacher_cfg(), device=dev)
+    if not args.separate_towers:
+        # both models load the same frozen CLIP checkpoint in the reference's recipe (one --image_tower flag): give the
+        # random-init teacher tower the student's weights, which lets the trainer compute the image features once per batch
+        teacher.get_image_tower().load_state_dict(student.get_image_tower().state_dict())
     student.train(); teacher.eval()
     n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
     gb = GradBuffer(student)
@@ -262,6 +267,8 @@ def main():
                                    f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
                        "micro_batch_per_gpu": B, "global_batch": B * world, "seq_len": 2048, "response_tokens": 512,
                        "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)",
+                       "image_tower": ("different weights per model, run twice" if args.separate_towers or args.stage != "mimic" else
+                                       "student and teacher towers bit-identical (same checkpoint): features computed once per batch, shared"),
                        "teacher_pipelining": "teacher fwd of batch i+1 on a side stream under the student's step i" if pipelined else "off",
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),

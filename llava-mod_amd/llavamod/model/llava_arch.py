@@ -127,7 +127,13 @@ class LlavaMetaForCausalLM:
         return None
 
     def encode_images(self, images):                          # llava_arch.py:143-148
-        feats = self.get_model().get_image_tower()(images)    # [B, 1+P, Dv], CLS skipped inside the projector
+        # `_shared_tower_feats` (set by a trainer for ONE call): tower output computed by another model whose frozen
+        # tower is bit-identical (student and teacher load the same CLIP checkpoint) — the tower is not run again.
+        feats = getattr(self, "_shared_tower_feats", None)
+        self._shared_tower_feats = None
+        if feats is None:
+            feats = self.get_model().get_image_tower()(images)    # [B, 1+P, Dv], CLS skipped inside the projector
+        self._last_tower_feats = feats
         return self.get_model().mm_projector.forward_image(feats)
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,

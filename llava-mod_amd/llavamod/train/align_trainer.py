@@ -53,7 +53,22 @@ class AlignTrainer:
         with torch.no_grad():
             t_rows, _, t_info = self.ref_model.forward_hidden(**batch, plan_fn=lambda info: self._plan(info, self._dev()))
             t_logits = ops.linear_fwd(t_rows, self.ref_model.head())
-        return SimpleNamespace(plan=t_info.plan, logits=t_logits, event=None)
+        feats = getattr(self.ref_model, "_last_tower_feats", None) if self._towers_identical() else None
+        return SimpleNamespace(plan=t_info.plan, logits=t_logits, event=None, tower_feats=feats)
+
+    def _towers_identical(self):
+        """Student and teacher normally load the SAME frozen CLIP checkpoint (`--image_tower` is one flag in the
+        reference's shells); when their towers are frozen and bit-identical the features are computed once per batch
+        and shared (the reference runs the tower twice).  Checked once, on the actual weights."""
+        if getattr(self, "_tower_shared", None) is None:
+            ok = False
+            ts, tt = self.model.get_image_tower(), self.ref_model.get_image_tower()
+            if ts is not None and tt is not None and getattr(self, "share_image_tower", True):
+                a, b = ts.state_dict(), tt.state_dict()
+                ok = (a.keys() == b.keys() and not any(p.requires_grad for p in ts.parameters())
+                      and all(a[k].shape == b[k].shape and torch.equal(a[k], b[k]) for k in a))
+            self._tower_shared = ok
+        return self._tower_shared
 
     @staticmethod
     def _batch_of(inputs):
@@ -81,9 +96,12 @@ class AlignTrainer:
         elif teacher.event is not None:                       # produced on the side stream: order and pin its memory
             cur = torch.cuda.current_stream()
             cur.wait_event(teacher.event)
-            for t in [teacher.logits] + [v for v in vars(teacher.plan).values() if torch.is_tensor(v)]:
-                t.record_stream(cur)
+            for t in [teacher.logits, teacher.tower_feats] + [v for v in vars(teacher.plan).values() if torch.is_tensor(v)]:
+                if t is not None:
+                    t.record_stream(cur)
         teacher_plan, t_logits = teacher.plan, teacher.logits
+        if teacher.tower_feats is not None:
+            model._shared_tower_feats = teacher.tower_feats          # consumed by the student's encode_images below
         # same inputs => same spliced labels => same loss rows: the student's last (dense) layer is trimmed the same way
         s_hidden, moe_list, s_info = model.forward_hidden(**batch, plan_fn=lambda info: copy.copy(teacher_plan))
         plan = s_info.plan

@@ -340,3 +340,41 @@ def test_prefetched_teacher_equals_inline():
                                         if getattr(p, "main_grad", None) is not None}))
         assert grads[0][0] == grads[1][0]
         assert all(torch.equal(grads[0][1][n], grads[1][1][n]) for n in grads[0][1])
+
+
+def test_shared_image_tower_features_are_exact():
+    """With bit-identical frozen towers the trainer runs CLIP once per batch; loss and gradients do not change."""
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    for p in student.get_image_tower().parameters():
+        p.requires_grad = False
+    args = type("A", (), dict(moe_enable=True, distill_all_tokens=False, loss_type="kd_lm", moe_loss_enable=True))()
+    batch = _batch_from(g, "plain")
+    tr = AlignTrainer(student, teacher, args=args, align_vocab=512)
+    assert not tr._towers_identical()                         # the golden pair has different towers: nothing is shared
+    teacher.get_image_tower().load_state_dict(student.get_image_tower().state_dict())
+    res = []
+    for share in (True, False):
+        tr = AlignTrainer(student, teacher, args=args, align_vocab=512)
+        tr.share_image_tower = share
+        assert tr._towers_identical() == share
+        for p in student.parameters():
+            if getattr(p, "main_grad", None) is not None:
+                p.main_grad.zero_()
+        calls = {"n": 0}
+        tower = student.get_image_tower()
+        orig = tower.forward
+        tower.forward = lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), orig(*a, **k))[1]
+        loss = tr.compute_loss(student, batch)
+        loss.backward()
+        tower.forward = orig
+        assert calls["n"] == (0 if share else 1)              # the student's tower only runs when nothing is shared
+        res.append((float(loss), {n: p.main_grad.clone() for n, p in student.named_parameters()
+                                  if getattr(p, "main_grad", None) is not None}))
+    assert res[0][0] == res[1][0]
+    assert all(torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
