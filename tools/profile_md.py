@@ -13,7 +13,8 @@ def stats_md():
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     out = ["# rocprofv3 --kernel-trace --stats of the default bench workload (round 1, final)", "",
            "Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
-           "--no-cpu-baseline`", "",
+           "--no-cpu-baseline --no-teacher-prefetch` (teacher pipelining off so that kernel durations do not overlap; the "
+           "default bench line with pipelining on is in `*_bench_n1.json`).", "",
            f"{n_steps} steps (1 warm-up + 3 timed), micro-batch {line['config']['micro_batch_per_gpu']}, config 2.  Sum of kernel "
            f"time {tot / 1e6:.1f} ms = {tot / 1e6 / n_steps:.1f} ms/step; bench wall clock under the profiler "
            f"{line['ms_per_step']} ms/step ({line['value']} samples/s).  Model construction is inside the trace (torch "
@@ -43,7 +44,8 @@ def stats_md():
     for (k, nb), (n, ms) in sorted(by.items(), key=lambda t: -t[1][1])[:16]:
         out.append(f"| `{k}` | {nb} | {nb / 256:.2f} | {n} | {ms:.1f} |")
     open(dst + "_bench_kernel_stats.md", "w").write("\n".join(out) + "\n")
-    json.dump(line, open(dst + "_bench_n1.json", "w"), indent=1)
+    dflt = [l for l in open(f"{src}/bench_default.json") if l.startswith("{")]
+    json.dump(json.loads(dflt[-1]) if dflt else line, open(dst + "_bench_n1.json", "w"), indent=1)
 
 
 def pmc(run):
