@@ -1,0 +1,55 @@
+"""Collators reproduce the reference's batch contract (data/dataset.py:167-232, :434-505)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "llava-mod_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from llavamod.data import DataCollatorForDPODataset, DataCollatorForSupervisedDataset  # noqa: E402
+
+TOK = SimpleNamespace(pad_token_id=151646, model_max_length=12)
+
+
+def _inst(n, seed, n_img=1):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 1000, (n,), generator=g)
+    lab = ids.clone(); lab[: n // 2] = -100
+    imgs = [torch.randn(3, 4, 4, generator=g) for _ in range(n_img)]
+    return dict(input_ids=ids, labels=lab, image=imgs if n_img != 1 else imgs[0])
+
+
+def test_supervised_collator_contract():
+    inst = [_inst(5, 1), _inst(15, 2, n_img=2), _inst(9, 3)]
+    b = DataCollatorForSupervisedDataset(TOK)(inst)
+    ref_ids = pad_sequence([i["input_ids"] for i in inst], batch_first=True, padding_value=TOK.pad_token_id)[:, :12]
+    ref_lab = pad_sequence([i["labels"] for i in inst], batch_first=True, padding_value=-100)[:, :12]
+    assert torch.equal(b["input_ids"], ref_ids) and torch.equal(b["labels"], ref_lab)
+    assert torch.equal(b["attention_mask"], ref_ids.ne(TOK.pad_token_id)) and b["attention_mask"].dtype == torch.bool
+    assert len(b["images"]) == 4 and all(im.shape == (3, 4, 4) for im in b["images"])
+    assert b["images"][1] is inst[1]["image"][0] and b["images"][3] is inst[2]["image"]
+    with pytest.raises(ValueError):
+        DataCollatorForSupervisedDataset(TOK)([dict(input_ids=torch.ones(3, dtype=torch.long), labels=torch.ones(3, dtype=torch.long))])
+
+
+def test_dpo_collator_contract():
+    inst = []
+    for k in range(3):
+        c, r = _inst(6 + 4 * k, 10 + k), _inst(20 - 5 * k, 20 + k)
+        inst.append(dict(chosen_input_ids=c["input_ids"], chosen_labels=c["labels"], rejected_input_ids=r["input_ids"],
+                         rejected_labels=r["labels"], image=c["image"]))
+    b = DataCollatorForDPODataset(TOK)(inst)
+    for side in ("chosen", "rejected"):
+        ref = pad_sequence([i[f"{side}_input_ids"] for i in inst], batch_first=True, padding_value=TOK.pad_token_id)
+        assert torch.equal(b[f"{side}_input_ids"], ref)                      # no truncation on the DPO path
+        assert torch.equal(b[f"{side}_labels"], pad_sequence([i[f"{side}_labels"] for i in inst], batch_first=True, padding_value=-100))
+        assert torch.equal(b[f"{side}_attention_mask"], ref.ne(TOK.pad_token_id))
+    assert len(b["images"]) == 3
+    assert set(b) == {"chosen_input_ids", "chosen_labels", "chosen_attention_mask", "rejected_input_ids", "rejected_labels",
+                      "rejected_attention_mask", "images"}
