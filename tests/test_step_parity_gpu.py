@@ -378,3 +378,4 @@ def test_shared_image_tower_features_are_exact():
                                   if getattr(p, "main_grad", None) is not None}))
     assert res[0][0] == res[1][0]
     assert all(torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
+
