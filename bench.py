@@ -193,14 +193,16 @@ def main():
     # student's step i, so the two streams' MFMA-bound and HBM-bound kernels overlap.  Every step still runs exactly one
     # teacher forward and one student forward/backward/optimizer update; the device-wide synchronize() that closes the
     # timed region also waits for the last teacher pass.
-    pipelined = args.stage == "mimic" and not args.no_teacher_prefetch
-    state = {"teacher": trainer.prefetch_teacher(batches[0]) if pipelined else None}
+    pipelined = not args.no_teacher_prefetch
+    prefetch = trainer.prefetch_teacher if args.stage == "mimic" else trainer.prefetch_reference
+    state = {"teacher": prefetch(batches[0]) if pipelined else None}
 
     def step(i):
         gb.zero()
         if pipelined:
-            nxt = trainer.prefetch_teacher(batches[(i + 1) % 2])
-            loss = trainer.training_step(student, batches[i % 2], teacher=state["teacher"])
+            nxt = prefetch(batches[(i + 1) % 2])
+            kw = {"teacher" if args.stage == "mimic" else "reference": state["teacher"]}
+            loss = trainer.training_step(student, batches[i % 2], **kw)
             state["teacher"] = nxt
         else:
             loss = trainer.training_step(student, batches[i % 2])

@@ -80,19 +80,45 @@ class DPOTrainer:
         self._last_mean = mean
         return losses, cr, rj
 
-    def compute_loss(self, model, inputs, return_outputs=False):
+    @staticmethod
+    def _sides(inputs):
         ch = dict(input_ids=inputs["chosen_input_ids"], labels=inputs["chosen_labels"],
                   attention_mask=inputs["chosen_attention_mask"])
         rj = dict(input_ids=inputs["rejected_input_ids"], labels=inputs["rejected_labels"],
                   attention_mask=inputs["rejected_attention_mask"])
         if "images" in inputs:
             ch["images"] = inputs["images"]; rj["images"] = inputs["images"]
-        pc, pc_sft, pc_moe = self.get_logp(model, ch)
-        pr, _, pr_moe = self.get_logp(model, rj)
+        return ch, rj
+
+    def _reference_pass(self, ch, rj):
         assert self.ref_model is not None, "ref model can not be none!"
         with torch.no_grad():
             rc, *_ = self.get_logp(self.ref_model, ch)
             rr, *_ = self.get_logp(self.ref_model, rj)
+        return SimpleNamespace(chosen=rc, rejected=rr, event=None)
+
+    def prefetch_reference(self, inputs):
+        """Reference-model log-probabilities of a FUTURE batch on a side stream (the reference model is frozen); pass the
+        handle to `compute_loss(..., reference=handle)`.  Same pipelining as `AlignTrainer.prefetch_teacher`."""
+        if getattr(self, "_rstream", None) is None:
+            self._rstream = torch.cuda.Stream(device=next(self.ref_model.parameters()).device)
+        with torch.cuda.stream(self._rstream):
+            h = self._reference_pass(*self._sides(inputs))
+            h.event = torch.cuda.Event()
+            h.event.record(self._rstream)
+        return h
+
+    def compute_loss(self, model, inputs, return_outputs=False, reference=None):
+        ch, rj = self._sides(inputs)
+        pc, pc_sft, pc_moe = self.get_logp(model, ch)
+        pr, _, pr_moe = self.get_logp(model, rj)
+        if reference is None:
+            reference = self._reference_pass(ch, rj)
+        elif reference.event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(reference.event)
+            reference.chosen.record_stream(cur); reference.rejected.record_stream(cur)
+        rc, rr = reference.chosen, reference.rejected
         reward_losses, chosen_rewards, rejected_rewards = self.dpo_loss(pc, pr, rc, rr)
         reward_mean = self._last_mean                           # differentiable mean of reward_losses
         if pc_moe is not None and pr_moe is not None and bool(pc_moe) and bool(pr_moe):   # :614-616
@@ -110,8 +136,8 @@ class DPOTrainer:
         self.store_metrics({k: v.detach() for k, v in outputs.items()}, train_eval="train")
         return (total, outputs) if return_outputs else total
 
-    def training_step(self, model, inputs):
-        loss = self.compute_loss(model, inputs)
+    def training_step(self, model, inputs, reference=None):
+        loss = self.compute_loss(model, inputs, reference=reference)
         loss.backward()
         return loss.detach()
 

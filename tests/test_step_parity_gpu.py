@@ -379,3 +379,21 @@ def test_shared_image_tower_features_are_exact():
     assert res[0][0] == res[1][0]
     assert all(torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
 
+
+def test_prefetched_reference_equals_inline_dpo():
+    from llavamod.train.dpo_trainer import DPOTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    a, b = _batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")
+    pair = dict(chosen_input_ids=a["input_ids"], chosen_labels=a["labels"], chosen_attention_mask=a["attention_mask"],
+                rejected_input_ids=b["input_ids"], rejected_labels=b["labels"], rejected_attention_mask=b["attention_mask"],
+                images=a["images"])
+    tr = DPOTrainer(student, teacher, beta=0.1, loss_type="sigmoid")
+    h = tr.prefetch_reference(pair)
+    l1 = float(tr.compute_loss(student, pair, reference=h))
+    l2 = float(tr.compute_loss(student, pair))
+    assert l1 == l2
