@@ -1168,8 +1168,9 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
                       int batch, long long strideA, long long strideB, long long strideC,
                       const int* m_valid, const int* k_valid,
                       int act, int out_f32, int accumulate, hipStream_t stream) {
-  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
-  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if (M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;          // an empty problem dereferences nothing
+  if (!A || !B || !C) return LMOD_EINVAL;
   if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return LMOD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return LMOD_EINVAL;
   if (act < 0 || act > 2 || ldc < N) return LMOD_EINVAL;
@@ -1251,8 +1252,9 @@ int lmod_gemm_swiglu_bf16(const void* A, const void* W, void* act_out, void* gu_
 int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, void* dgu, int M, int N, int K, int lda,
                               int ldb, int ld_gu, int ld_dgu, int batch, long long strideA, long long strideB,
                               long long stride_gu, long long stride_dgu, const int* m_valid, hipStream_t stream) {
-  if (!A || !Bt || !gu || !dgu || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
-  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if (M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;          // an empty problem dereferences nothing
+  if (!A || !Bt || !gu || !dgu) return LMOD_EINVAL;
   if ((K & 7) || (N & 15) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ld_gu < 2 * N || ld_dgu < 2 * N ||
       (ld_gu & 7) || (ld_dgu & 7)) return LMOD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) || ((uintptr_t)gu & 15) || ((uintptr_t)dgu & 15) || (stride_gu & 7) ||
@@ -1299,8 +1301,9 @@ static int wgrad_pick_split(int M, int N, int K, int max_s) {
 
 int lmod_gemm_wgrad_bf16_nt(const void* At, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int b_kmajor, void* workspace, long long workspace_bytes, hipStream_t stream) {
-  if (!At || !B || !C || M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
-  if (M == 0 || N == 0) return LMOD_OK;
+  if (M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0) return LMOD_OK;          // an empty problem dereferences nothing
+  if (!At || !B || !C) return LMOD_EINVAL;
   // the workspace bounds the split: WGRAD_MAX_TILES semaphores (16 KiB) + s partial images of 256 KiB per tile
   long long cap = 0;
   if (workspace && !((uintptr_t)workspace & 15))
@@ -1342,8 +1345,9 @@ int lmod_gemm_wgrad_bf16_nt(const void* At, const void* B, float* C, int M, int 
 int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
                       long long strideA, long long strideB, long long strideC, const int* k_valid, int out_f32,
                       int accumulate, hipStream_t stream) {
-  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
-  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;
+  if (M < 0 || N < 0 || K < 0 || batch < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0 || batch == 0) return LMOD_OK;          // an empty problem dereferences nothing
+  if (!A || !B || !C) return LMOD_EINVAL;
   if ((M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < M || ldb < N || ldc < N || (ldc & 3)) return LMOD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || (strideA & 7) || (strideB & 7) || (strideC & 3))
     return LMOD_EINVAL;

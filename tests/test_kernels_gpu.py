@@ -597,3 +597,31 @@ def test_segment_wsum_and_dpo_loss():
         assert torch.allclose(dpc, a.grad, atol=1e-5), (lt, dpc, a.grad)
         assert torch.allclose(dpr, b.grad, atol=1e-5), (lt, dpr, b.grad)
         assert torch.allclose(cr, 0.1 * (pc - rc)) and torch.allclose(rj, 0.1 * (pr - rr))
+
+
+def test_abi_error_codes_and_empty_inputs():
+    """C-ABI behaviour at the edges: empty problems are a no-op (0), bad shapes / alignment / pointers are LMOD_EINVAL (-1),
+    shapes outside the compiled envelope LMOD_EUNSUPPORTED (-3); the Python binding turns them into exceptions."""
+    from llavamod import _hip
+    lib = _hip.load()
+    s = torch.cuda.current_stream().cuda_stream
+    a, b = rnd(64, 64, seed=80), rnd(64, 64, seed=81)
+    c = torch.zeros(64, 64, device=DEV, dtype=BF)
+    g = lambda M, N, Kd, lda=64, ldb=64, ldc=64, A=a, B=b, C=c: lib.lmod_gemm_bf16_nt(
+        A.data_ptr() if A is not None else None, B.data_ptr(), C.data_ptr(), None, M, N, Kd, lda, ldb, ldc, 1, 0, 0, 0, None, None, 0, 0, 0, s)
+    assert g(0, 64, 64) == 0 and g(64, 0, 64) == 0                      # empty: nothing launched, C untouched
+    assert c.abs().max().item() == 0
+    assert g(64, 64, 60) == -1                                          # K % 8
+    assert g(64, 64, 64, lda=60) == -1 and g(64, 64, 64, ldc=32) == -1  # leading dims
+    assert g(64, 64, 64, A=None) == -1                                  # NULL pointer
+    assert lib.lmod_gemm_bf16_nt(a.data_ptr() + 2, b.data_ptr(), c.data_ptr(), None, 64, 64, 64, 64, 64, 64, 1, 0, 0, 0,
+                                 None, None, 0, 0, 0, s) == -1          # misaligned A
+    assert g(64, 64, 64) == 0
+    q = rnd(128, 3 * 96, seed=82)
+    o = torch.empty(128, 96, device=DEV, dtype=BF)
+    assert lib.lmod_attn_fwd(q.data_ptr(), q.data_ptr(), q.data_ptr(), o.data_ptr(), None, None, 1, 128, 1, 1, 96, 288, 288, 288,
+                             96, 0.1, 1, s) == -3                       # head dim 96 is not compiled
+    with pytest.raises(RuntimeError, match="LMOD_EINVAL"):
+        K.gemm_nt(rnd(8, 12, seed=83), rnd(8, 12, seed=84))             # K = 12 through the binding
+    assert K.gemm_nt(a[:0], b).shape == (0, 64)                         # zero rows: allocates, launches nothing
+    torch.cuda.synchronize()
