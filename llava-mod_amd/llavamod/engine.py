@@ -249,7 +249,14 @@ def init_distributed():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL's communication streams at HIGH priority: the step's compute stream is a high-priority stream too (the
+        # prefetched teacher pass runs below both), and a default-priority all-reduce would starve behind it
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:                                     # older torch builds: fall back to the environment switch
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=opts)
     else:
         dist.init_process_group("gloo")
     return rank, local, world
