@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=16)
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer-overlap", action="store_true",
+                    help="just-in-time AdamW on a second stream (bit-identical; measured 0.3 %% slower than serial, off by default)")
     ap.add_argument("--separate-towers", action="store_true", help="different random CLIP towers: both are run (no feature sharing)")
     ap.add_argument("--no-teacher-prefetch", action="store_true", help="run the teacher forward inline (A/B of the pipelining)")
     ap.add_argument("--ep", type=int, default=1, help="expert-parallel group size (config 5: --experts 8 --ep 8)")
@@ -207,7 +209,7 @@ def main():
         else:
             loss = trainer.training_step(student, batches[i % 2])
         dp.finish()                      # spans were all-reduced asynchronously as backward produced them
-        opt.step(grad_scale=1.0 / world, lr=warmup_cosine(i, max(total, 100), 2e-5))
+        opt.step(grad_scale=1.0 / world, lr=warmup_cosine(i, max(total, 100), 2e-5), overlap=args.optimizer_overlap)
         return loss
 
     if pipelined:
@@ -274,7 +276,8 @@ def main():
                                    f", CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({args.experts} experts, top-2, cf 1.5, 12 MoE layers, "
                                    f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
                        "micro_batch_per_gpu": B, "global_batch": B * world, "seq_len": 2048, "response_tokens": 512,
-                       "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)",
+                       "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)" + ("" if not args.optimizer_overlap else
+                                    ", just-in-time: spans updated on a second stream in forward order, gradients cleared in the same pass"),
                        "image_tower": ("different weights per model, run twice" if args.separate_towers or args.stage != "mimic" else
                                        "student and teacher towers bit-identical (same checkpoint): features computed once per batch, shared"),
                        "teacher_pipelining": ("teacher fwd of batch i+1 on a side stream under the student's step i (student on a "

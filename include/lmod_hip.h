@@ -118,9 +118,10 @@ int lmod_im2col_patch(const void* pixels, void* out, int B, int image_size, int 
 int lmod_vit_embed(const void* patch_emb, const void* cls, const void* pos, void* out, int B, int n_patches, int D,
                    hipStream_t stream);
 /* torch.optim.AdamW step (HF `adamw_torch`, config/args.py:78) on fp32 master weights with a bf16
- * working copy; grad is fp32, scaled by grad_scale first. */
-int lmod_adamw_step(float* master, void* param_bf16, const float* grad, float* m, float* v, long long n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+ * working copy; grad is fp32, scaled by grad_scale first.  zero_grad != 0: the gradient is cleared in the same pass
+ * (the optimizer's zero_grad(), without a separate memset of the gradient buffer). */
+int lmod_adamw_step(float* master, void* param_bf16, float* grad, float* m, float* v, long long n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad,
                     hipStream_t stream);
 
 /* ---- attention -------------------------------------------------------------------------------

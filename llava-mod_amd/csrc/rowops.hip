@@ -382,11 +382,12 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const bf16_t* __restrict
 // fp32 master/m/v, fp32 grad, bf16 working copy refreshed in the same pass.
 // Matches torch.optim.AdamW (HF `adamw_torch`, reference config/args.py:78) step arithmetic.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, bf16_t* __restrict__ param,
-                                                   const float* __restrict__ grad, float* __restrict__ m,
+                                                   float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2, float gscale) {
+                                                   float eps, float wd, float bc1, float bc2, float gscale, int zero_grad) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float g = grad[i] * gscale;
+    if (zero_grad) grad[i] = 0.f;            // the gradient buffer is consumed: no separate memset before the next step
     float p = master[i];
     p *= (1.f - lr * wd);
     const float mi = b1 * m[i] + (1.f - b1) * g;
@@ -520,14 +521,14 @@ int lmod_vit_embed(const void* patch_emb, const void* cls, const void* pos, void
   return lmod_launch_status();
 }
 
-int lmod_adamw_step(float* master, void* param_bf16, const float* grad, float* m, float* v, long long n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+int lmod_adamw_step(float* master, void* param_bf16, float* grad, float* m, float* v, long long n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad,
                     hipStream_t stream) {
   if (!master || !param_bf16 || !grad || !m || !v || n < 0 || step < 1) return LMOD_EINVAL;
   if (n == 0) return LMOD_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, master, (bf16_t*)param_bf16, grad, m, v,
-                     n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                     n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, zero_grad);
   return lmod_launch_status();
 }
 

@@ -32,6 +32,10 @@ def save_checkpoint(model, out_dir, max_shard_bytes=5 << 30, projector_file=True
     """Write `model-XXXXX-of-YYYYY.safetensors` + index (HF layout) and, like the reference's trainer, the projector
     weights alone as `mm_projector.bin`.  Returns the list of files written."""
     os.makedirs(out_dir, exist_ok=True)
+    from .engine import fused_weights_of
+    for fw in fused_weights_of(model):          # orders this stream after any optimizer update still in flight
+        if fw.w is not None:
+            fw.ensure()
     sd = {k: v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
     shards, cur, size = [], {}, 0
     for k, v in sd.items():

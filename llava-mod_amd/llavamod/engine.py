@@ -112,7 +112,10 @@ class GradBuffer:
         self.numel = total
 
     def zero(self):
-        self.flat.zero_()
+        if getattr(self, "clean", False):        # the optimizer cleared every span in its own pass (HipAdamW overlap)
+            self.clean = False
+        else:
+            self.flat.zero_()
         for kind, obj, _ in self.spans:          # forget uses that never saw a backward (eval-style forwards)
             if kind == "w":
                 obj.pending = 0
@@ -208,26 +211,64 @@ class HipAdamW:
         self.v = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
         self.step_count = 0
         self._scratch = {}
+        self._stream = None
         for (kind, obj, n), off in zip(gb.spans, gb.offsets):
             src = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
             self.master[off:off + n].copy_(src.reshape(-1).float())
 
-    def step(self, grad_scale=1.0, lr=None):
+    def _update(self, kind, obj, off, n, lr, grad_scale, zero_grad):
+        tgt = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
+        if tgt.dtype == BF16:
+            pb = tgt
+        else:                                   # fp32 parameter (router wg): bf16 copy goes to scratch
+            pb = self._scratch.setdefault(n, torch.empty(n, device=tgt.device, dtype=BF16))
+        K.adamw_step(self.master[off:off + n], pb, self.gb.flat[off:off + n], self.m[off:off + n],
+                     self.v[off:off + n], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                     grad_scale, zero_grad=zero_grad)
+        if tgt.dtype != BF16:
+            tgt.reshape(-1).copy_(self.master[off:off + n])
+        if kind == "w":
+            obj._wt_version = None      # the kernel wrote behind torch's back: invalidate the cached W^T
+
+    def step(self, grad_scale=1.0, lr=None, overlap=False):
+        """One AdamW update of every span.  overlap=True is the just-in-time form: the fused weights (99.9 % of the
+        bytes) are updated on the optimizer's own stream in the order the next forward will touch them, each one
+        publishing an event that `FusedWeight.ensure()` waits on, so this HBM-bound pass runs under the next step's
+        forward GEMMs instead of in front of them; every span also clears its gradient in the same pass (GradBuffer.zero()
+        then skips the memset).  Arithmetic and results are identical to the serial form.  Call `sync()` before reading
+        weights outside a forward."""
         self.step_count += 1
         lr = self.lr if lr is None else lr
-        for (kind, obj, n), off in zip(self.gb.spans, self.gb.offsets):
-            tgt = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
-            if tgt.dtype == BF16:
-                pb = tgt
-            else:                                   # fp32 parameter (router wg): bf16 copy goes to scratch
-                pb = self._scratch.setdefault(n, torch.empty(n, device=tgt.device, dtype=BF16))
-            K.adamw_step(self.master[off:off + n], pb, self.gb.flat[off:off + n], self.m[off:off + n],
-                         self.v[off:off + n], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                         grad_scale)
-            if tgt.dtype != BF16:
-                tgt.reshape(-1).copy_(self.master[off:off + n])
-            if kind == "w":
-                obj._wt_version = None      # the kernel wrote behind torch's back: invalidate the cached W^T
+        spans = list(zip(self.gb.spans, self.gb.offsets))
+        if not overlap:
+            for (kind, obj, n), off in spans:
+                self._update(kind, obj, off, n, lr, grad_scale, False)
+            return
+        deferred, inline = {}, []
+        for (kind, obj, n), off in spans:
+            if kind in ("w", "b") and obj._use_seq is not None:
+                deferred.setdefault(id(obj), (obj, []))[1].append((kind, off, n))
+            else:
+                inline.append((kind, obj, off, n))
+        for kind, obj, off, n in inline:                     # small / not-yet-ordered spans: in line
+            self._update(kind, obj, off, n, lr, grad_scale, True)
+        cur = torch.cuda.current_stream()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.gb.flat.device, priority=cur.priority)
+        self._stream.wait_stream(cur)                        # gradients (and their all-reduce) are final on `cur`
+        with torch.cuda.stream(self._stream):
+            for obj, parts in sorted(deferred.values(), key=lambda t: t[0]._use_seq):
+                for kind, off, n in parts:
+                    self._update(kind, obj, off, n, lr, grad_scale, True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                obj._ready = ev
+        self.gb.clean = True
+
+    def sync(self):
+        """Make the current stream wait for an overlapped step (before reading weights outside a forward)."""
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
 
 
 def warmup_cosine(step, total_steps, base_lr, warmup_ratio=0.03):

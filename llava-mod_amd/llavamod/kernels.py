@@ -221,9 +221,9 @@ def vit_embed(patch_emb, cls, pos, B, n_patches):
     return out
 
 
-def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, zero_grad=False):
     call("lmod_adamw_step", ptr(master), ptr(param), ptr(grad), ptr(m), ptr(v), master.numel(), float(lr),
-         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale))
+         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), int(zero_grad))
 
 
 # ------------------------------------------------------------------------------------------ attention

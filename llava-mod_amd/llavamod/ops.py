@@ -33,6 +33,8 @@ class FusedWeight:
         self.bias_main_grad = None
         self.pending = 0                 # wgrad contributions still to come in the current backward
         self.grad_ready_hook = None      # engine: called once the last contribution has been enqueued
+        self._ready = None               # event of an optimizer update still running on the optimizer's stream
+        self._use_seq = None             # position in the forward's first-use order (for the just-in-time optimizer)
 
     def note_use(self):
         """A forward that will later accumulate into main_grad (called by the fused blocks)."""
@@ -57,7 +59,18 @@ class FusedWeight:
                 yield p, (buf[e, r:r + p.shape[0]] if self.stacked else buf[r:r + p.shape[0]])
                 r += p.shape[0]
 
+    _SEQ = [0]
+
     def ensure(self):
+        """Called by every forward right before the weight is used: (re)build the fused storage if needed and, if the
+        optimizer is still updating this weight on its own stream (engine.HipAdamW overlap), order this stream after it."""
+        ev = self._ready
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._ready = None
+        if self._use_seq is None:
+            FusedWeight._SEQ[0] += 1
+            self._use_seq = FusedWeight._SEQ[0]
         p0 = self.groups[0][0]
         ok = self.w is not None and self.w.device == p0.device
         if ok:

@@ -382,6 +382,12 @@ def test_gather_im2col_vitembed_adamw():
         K.adamw_step(master, pb, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.1, step)
     close(master, ref_p.detach(), "adamw", rtol=1e-5, afrac=1e-6)
     close(pb, master.to(BF), "adamw bf16 copy", rtol=0, afrac=0)
+    # zero_grad: same update, gradient cleared in the same pass
+    m2, v2, ms2, pb2, g2 = m.clone(), v.clone(), master.clone(), pb.clone(), g.clone()
+    K.adamw_step(master, pb, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.1, 4)
+    K.adamw_step(ms2, pb2, g2, m2, v2, 1e-2, 0.9, 0.999, 1e-8, 0.1, 4, zero_grad=True)
+    assert torch.equal(master, ms2) and torch.equal(pb, pb2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert g2.abs().max().item() == 0 and torch.equal(g, g2 + g)
 
 
 # ------------------------------------------------------------------------------------------ attention

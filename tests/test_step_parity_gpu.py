@@ -397,3 +397,40 @@ def test_prefetched_reference_equals_inline_dpo():
     l1 = float(tr.compute_loss(student, pair, reference=h))
     l2 = float(tr.compute_loss(student, pair))
     assert l1 == l2
+
+
+def test_overlapped_optimizer_is_exact_over_steps():
+    """Just-in-time AdamW (second stream, forward order, gradients cleared in the same pass) == serial AdamW + memset,
+    bit for bit, over several optimizer steps (weights, moments, losses)."""
+    from llavamod.engine import GradBuffer, HipAdamW
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    batches = [_batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")]
+    runs = []
+    for overlap in (False, True):
+        student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+        for m in student.moe_layers():
+            m.deterministic = True
+        tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                                   loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=512)
+        gb = GradBuffer(student)
+        opt = HipAdamW(gb, lr=1e-3, weight_decay=0.01)
+        losses = []
+        for i in range(4):
+            gb.zero()
+            losses.append(float(tr.training_step(student, batches[i % 2])))
+            opt.step(grad_scale=1.0, overlap=overlap)
+            if overlap and i >= 1:
+                assert gb.clean and any(fw._ready is not None for _, fw, _ in gb.spans if hasattr(fw, "_ready"))
+        opt.sync()
+        torch.cuda.synchronize()
+        assert gb.flat.abs().max().item() == 0 if overlap else True        # gradients were cleared by the optimizer pass
+        runs.append((losses, opt.master.clone(), opt.m.clone(), opt.v.clone(),
+                     {k: v.clone() for k, v in student.state_dict().items()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][0][0] != runs[0][0][2]                                  # the weights really moved between steps
+    for a, b in zip(runs[0][1:4], runs[1][1:4]):
+        assert torch.equal(a, b)
+    assert all(torch.equal(runs[0][4][k], runs[1][4][k]) for k in runs[0][4])
