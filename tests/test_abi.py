@@ -54,3 +54,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _hip.load()
+
+
+def test_product_path_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under llava-mod_amd/ may import or execute it, nothing may read
+    /root/reference, and there is no CPU fallback module behind the kernels."""
+    import re
+    root = os.path.join(ROOT, "llava-mod_amd")
+    bad = []
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h")):
+                continue
+            src = open(os.path.join(dp, f), encoding="utf-8").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "/root/reference" in src:
+                bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    # bench.py and __graft_entry__.py may use the oracle only inside cpu_baseline() / smoke()
+    for name, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        lines = open(os.path.join(ROOT, name), encoding="utf-8").read().split("\n")
+        for i, line in enumerate(lines):
+            if re.match(r"\s*(from|import)\s+oracle\b", line):
+                enclosing = next((l for l in reversed(lines[:i]) if re.match(r"def \w+", l)), "")
+                assert enclosing.startswith(f"def {allowed}"), (name, i + 1, enclosing)
