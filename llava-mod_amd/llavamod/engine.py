@@ -230,7 +230,7 @@ class HipAdamW:
         if kind == "w":
             obj._wt_version = None      # the kernel wrote behind torch's back: invalidate the cached W^T
 
-    def step(self, grad_scale=1.0, lr=None, overlap=False):
+    def step(self, grad_scale=1.0, lr=None, overlap=False, clear_grads=False):
         """One AdamW update of every span.  overlap=True is the just-in-time form: the fused weights (99.9 % of the
         bytes) are updated on the optimizer's own stream in the order the next forward will touch them, each one
         publishing an event that `FusedWeight.ensure()` waits on, so this HBM-bound pass runs under the next step's
@@ -241,8 +241,12 @@ class HipAdamW:
         lr = self.lr if lr is None else lr
         spans = list(zip(self.gb.spans, self.gb.offsets))
         if not overlap:
+            # clear_grads: every span zeroes its gradient in the same pass, so the next GradBuffer.zero() skips its
+            # 8 GB memset (optimizer.zero_grad() folded into the update)
             for (kind, obj, n), off in spans:
-                self._update(kind, obj, off, n, lr, grad_scale, False)
+                self._update(kind, obj, off, n, lr, grad_scale, clear_grads)
+            if clear_grads:
+                self.gb.clean = True
             return
         deferred, inline = {}, []
         for (kind, obj, n), off in spans:

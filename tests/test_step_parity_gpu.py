@@ -409,7 +409,7 @@ def test_overlapped_optimizer_is_exact_over_steps():
     g = U.load_golden("gpusmall_mimic.safetensors")
     batches = [_batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")]
     runs = []
-    for overlap in (False, True):
+    for overlap in (False, True, "serial+clear"):
         student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
         for m in student.moe_layers():
             m.deterministic = True
@@ -421,16 +421,21 @@ def test_overlapped_optimizer_is_exact_over_steps():
         for i in range(4):
             gb.zero()
             losses.append(float(tr.training_step(student, batches[i % 2])))
+            if overlap == "serial+clear":
+                opt.step(grad_scale=1.0, clear_grads=True)
+                assert gb.clean and gb.flat.abs().max().item() == 0
+                continue
             opt.step(grad_scale=1.0, overlap=overlap)
             if overlap and i >= 1:
                 assert gb.clean and any(fw._ready is not None for _, fw, _ in gb.spans if hasattr(fw, "_ready"))
         opt.sync()
         torch.cuda.synchronize()
-        assert gb.flat.abs().max().item() == 0 if overlap else True        # gradients were cleared by the optimizer pass
+        assert gb.flat.abs().max().item() == 0 if overlap is True else True    # gradients were cleared by the optimizer pass
         runs.append((losses, opt.master.clone(), opt.m.clone(), opt.v.clone(),
                      {k: v.clone() for k, v in student.state_dict().items()}))
-    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert runs[0][0][0] != runs[0][0][2]                                  # the weights really moved between steps
-    for a, b in zip(runs[0][1:4], runs[1][1:4]):
-        assert torch.equal(a, b)
-    assert all(torch.equal(runs[0][4][k], runs[1][4][k]) for k in runs[0][4])
+    for other in runs[1:]:
+        assert runs[0][0] == other[0], (runs[0][0], other[0])
+        for a, b in zip(runs[0][1:4], other[1:4]):
+            assert torch.equal(a, b)
+        assert all(torch.equal(runs[0][4][k], other[4][k]) for k in runs[0][4])
