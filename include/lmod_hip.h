@@ -141,7 +141,7 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);
 /* top-k (k in {1,2}) gating with capacity C: token-order slot assignment, drops, renormalised
  * combine weights, l_aux, exp_counts, slots_used[E] (live rows per capacity slab).  noise: additive [T,E]
- * noise for the 2nd choice or NULL. */
+ * noise for the 2nd choice or NULL.  scratch: 2*T + 24*ceil(T/512) int32. */
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
                   int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream);

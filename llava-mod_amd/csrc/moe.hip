@@ -94,96 +94,104 @@ __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict_
   }
 }
 
-// ---------------------------------------------------------------- token-order prefix (single block)
+// ---------------------------------------------------------------- token-order prefix (three small launches)
 // loc1[t] = #{t' < t : idx1[t'] == idx1[t]} ; loc2[t] = #{t' < t : idx2[t'] == idx2[t]} + count1[idx2[t]]
 // (cumsum(mask,0)-1 and the "+ sum(mask1)" offset of top2gating).  Also exp_counts, sum of gates per
 // expert (me*T) and l_aux = mean(me*ce)*E*E.
-__global__ __launch_bounds__(1024) void moe_scan_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
-                                                       const float* __restrict__ gates, int* __restrict__ loc1,
-                                                       int* __restrict__ loc2, int* __restrict__ exp_counts,
-                                                       float* __restrict__ gate_sum, float* __restrict__ l_aux,
-                                                       int* __restrict__ slots_used, int T, int E, int k, int C) {
-  extern __shared__ int sh[];                // [2*MAXE][1024] counts, then scratch
-  int* cnt = sh;                             // cnt[(j*MAXE+e)*1024 + tid]
-  float* gsum = (float*)(sh + 2 * MAXE * 1024);   // [MAXE][16] per-wave partials
-  const int tid = threadIdx.x;
-  const int chunk = (T + 1023) / 1024;
-  const int lo = min(tid * chunk, T), hi = min(lo + chunk, T);
-  int c1[MAXE], c2[MAXE]; float gs[MAXE];
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) { c1[e] = 0; c2[e] = 0; gs[e] = 0.f; }
-  for (int t = lo; t < hi; ++t) {
-    const int a = idx1[t];
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      c1[e] += (a == e);
-      if (e < E) gs[e] += gates[(long long)t * E + e];
-    }
-    if (k >= 2) { const int b = idx2[t];
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) c2[e] += (b == e); }
-  }
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) { cnt[e * 1024 + tid] = c1[e]; cnt[(MAXE + e) * 1024 + tid] = c2[e]; }
-  // gate sums: wave reduce then 16 partials
+// A single-block scan left the chip idle for ~190 us per MoE layer; now: (1) every 512-token block counts its picks per
+// expert and sums its gates, (2) one small block turns the per-block counts into exclusive bases (fixed order, so the
+// gate sums / l_aux are deterministic), (3) every block ranks its tokens with wave ballots and adds its base.
+// part layout (caller scratch, ints): [NB][2*MAXE] counts -> bases, then [NB][MAXE] gate partial sums (as floats).
+#define SCAN_BLK 512
+__global__ __launch_bounds__(SCAN_BLK) void moe_count_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
+                                                            const float* __restrict__ gates, int* __restrict__ part,
+                                                            float* __restrict__ gpart, int T, int E, int k) {
+  __shared__ int wc[SCAN_BLK / 64][2 * MAXE];
+  __shared__ float wg[SCAN_BLK / 64][MAXE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x * SCAN_BLK + tid;
+  const int a = (t < T) ? idx1[t] : -1, b = (t < T && k >= 2) ? idx2[t] : -1;
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) {
-    const float s = wave_sum(gs[e]);
-    if ((tid & 63) == 0) gsum[e * 16 + (tid >> 6)] = s;
+    const int c1 = __popcll(__ballot(a == e)), c2 = __popcll(__ballot(b == e));
+    const float gs = wave_sum((t < T && e < E) ? gates[(long long)t * E + e] : 0.f);
+    if (lane == 0) { wc[w][e] = c1; wc[w][MAXE + e] = c2; wg[w][e] = gs; }
   }
   __syncthreads();
-  // exclusive scan of each of the 2*MAXE rows over 1024 entries: wave w scans row w (16 rows, 16 waves)
-  {
-    const int w = tid >> 6, lane = tid & 63;
-    int* row = cnt + w * 1024;
-    int carry = 0;
-    for (int base = 0; base < 1024; base += 64) {
-      const int v = row[base + lane];
-      int inc = v;
+  if (tid < 2 * MAXE) {
+    int s = 0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
-      row[base + lane] = carry + inc - v;
-      carry += __shfl(inc, 63, 64);
-    }
-    // row total == carry (held by every lane of wave w)
-    if (lane == 0) gsum[MAXE * 16 + w] = __int_as_float(carry);
+    for (int x = 0; x < SCAN_BLK / 64; ++x) s += wc[x][tid];
+    part[blockIdx.x * 2 * MAXE + tid] = s;
+  } else if (tid >= 64 && tid < 64 + MAXE) {
+    float s = 0.f;
+#pragma unroll
+    for (int x = 0; x < SCAN_BLK / 64; ++x) s += wg[x][tid - 64];
+    gpart[blockIdx.x * MAXE + tid - 64] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void moe_bases_kernel(int* __restrict__ part, const float* __restrict__ gpart, int nb,
+                                                      int* __restrict__ exp_counts, float* __restrict__ gate_sum,
+                                                      float* __restrict__ l_aux, int* __restrict__ slots_used, int T, int E,
+                                                      int k, int C) {
+  __shared__ int tot[2 * MAXE];
+  __shared__ float gsum[MAXE];
+  const int tid = threadIdx.x;
+  if (tid < 2 * MAXE) {                      // thread = (pick, expert): exclusive prefix over the blocks, in block order
+    int run = 0;
+    for (int x = 0; x < nb; ++x) { const int c = part[x * 2 * MAXE + tid]; part[x * 2 * MAXE + tid] = run; run += c; }
+    tot[tid] = run;
+  } else if (tid >= 32 && tid < 32 + MAXE) {
+    float s = 0.f;
+    for (int x = 0; x < nb; ++x) s += gpart[x * MAXE + tid - 32];
+    gsum[tid - 32] = s;
   }
   __syncthreads();
-  int tot1[MAXE];
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) tot1[e] = __float_as_int(gsum[MAXE * 16 + e]);
-  // second pass: assign locations
-  int r1[MAXE], r2[MAXE];
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) { r1[e] = cnt[e * 1024 + tid]; r2[e] = cnt[(MAXE + e) * 1024 + tid] + tot1[e]; }
-  for (int t = lo; t < hi; ++t) {
-    const int a = idx1[t];
-    int v = 0;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) if (a == e) { v = r1[e]; r1[e]++; }
-    loc1[t] = v;
-    if (k >= 2) {
-      const int b = idx2[t];
-      int u = 0;
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) if (b == e) { u = r2[e]; r2[e]++; }
-      loc2[t] = u;
-    }
+  if (tid >= MAXE && tid < 2 * MAXE) {       // second picks queue behind ALL first picks of the same expert
+    const int off = tot[tid - MAXE];
+    for (int x = 0; x < nb; ++x) part[x * 2 * MAXE + tid] += off;
   }
   if (tid == 0) {
     float la = 0.f;
     for (int e = 0; e < E; ++e) {
-      float s = 0.f;
-      for (int w = 0; w < 16; ++w) s += gsum[e * 16 + w];
-      gate_sum[e] = s;
-      exp_counts[e] = tot1[e];
+      gate_sum[e] = gsum[e];
+      exp_counts[e] = tot[e];
       // capacity slots are filled densely from 0: first picks, then second picks behind them
-      const int tot2 = (k >= 2) ? __float_as_int(gsum[MAXE * 16 + MAXE + e]) : 0;
-      slots_used[e] = min(C, tot1[e] + tot2);
-      la += (s / (float)T) * ((float)tot1[e] / (float)T);
+      slots_used[e] = min(C, tot[e] + ((k >= 2) ? tot[MAXE + e] : 0));
+      la += (gsum[e] / (float)T) * ((float)tot[e] / (float)T);
     }
     // top2gating: mean(me*ce)*E*E ; top1gating: sum(me*ce)*E — both equal E * sum_e(me*ce)
     l_aux[0] = la * (float)E;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_BLK) void moe_rank_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
+                                                           const int* __restrict__ part, int* __restrict__ loc1,
+                                                           int* __restrict__ loc2, int T, int k) {
+  __shared__ int wc[SCAN_BLK / 64][2 * MAXE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x * SCAN_BLK + tid;
+  const int a = (t < T) ? idx1[t] : -1, b = (t < T && k >= 2) ? idx2[t] : -1;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int r1 = 0, r2 = 0;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const unsigned long long m1 = __ballot(a == e), m2 = __ballot(b == e);
+    if (a == e) r1 = __popcll(m1 & below);
+    if (b == e) r2 = __popcll(m2 & below);
+    if (lane == 0) { wc[w][e] = __popcll(m1); wc[w][MAXE + e] = __popcll(m2); }
+  }
+  __syncthreads();
+  if (t >= T) return;
+  const int* base = part + blockIdx.x * 2 * MAXE;
+  int p1 = base[a] + r1;
+  for (int x = 0; x < w; ++x) p1 += wc[x][a];
+  loc1[t] = p1;
+  if (k >= 2) {
+    int p2 = base[MAXE + b] + r2;
+    for (int x = 0; x < w; ++x) p2 += wc[x][MAXE + b];
+    loc2[t] = p2;
   }
 }
 
@@ -418,7 +426,8 @@ int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, in
 
 // Full gating decision from logits.  noise: [T,E] additive (Gumbel) noise for the 2nd pick, or NULL.
 // Outputs: gates[T,E] f32; idx1/idx2/slot1/slot2 [T] i32; w1/w2 [T] f32; slot_token [E*C] i32 (-1 empty);
-// slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.  scratch: 2*T i32 (loc1, loc2).
+// slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.
+// scratch: 2*T + 24*ceil(T/512) i32 (loc1, loc2, per-block pick counts / bases and gate partial sums).
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
                   int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream) {
@@ -426,15 +435,14 @@ int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, 
       !slots_used || !scratch || T <= 0 || E <= 0 || E > MAXE || (k != 1 && k != 2) || C <= 0) return LMOD_EINVAL;
   if (k == 2 && (!idx2 || !slot2 || !w2)) return LMOD_EINVAL;
   int* loc1 = scratch; int* loc2 = scratch + T;
+  const int nb = (T + SCAN_BLK - 1) / SCAN_BLK;
+  int* part = scratch + 2 * (long long)T;                       // [nb][2*MAXE] ints
+  float* gpart = (float*)(part + (long long)nb * 2 * MAXE);     // [nb][MAXE] floats
   hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k);
-  const size_t sh = (size_t)2 * MAXE * 1024 * 4 + (MAXE * 16 + 16) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)moe_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), sh, stream, idx1, idx2, gates, loc1, loc2, exp_counts,
-                     gate_sum, l_aux, slots_used, T, E, k, C);
+  hipLaunchKernelGGL(moe_count_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, gates, part, gpart, T, E, k);
+  hipLaunchKernelGGL(moe_bases_kernel, dim3(1), dim3(64), 0, stream, part, gpart, nb, exp_counts, gate_sum, l_aux, slots_used,
+                     T, E, k, C);
+  hipLaunchKernelGGL(moe_rank_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, part, loc1, loc2, T, k);
   if (hipMemsetAsync(slot_token, 0xFF, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   if (hipMemsetAsync(slot_w, 0, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   hipLaunchKernelGGL(moe_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, loc1, loc2,

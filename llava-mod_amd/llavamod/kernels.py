@@ -275,7 +275,7 @@ def moe_gate(logits, k, C, noise=None):
     st.slot_token = torch.empty(E * C, **i32); st.slot_w = torch.empty(E * C, **f32)
     st.exp_counts = torch.empty(E, **i32); st.gate_sum = torch.empty(E, **f32); st.l_aux = torch.empty(1, **f32)
     st.slots_used = torch.empty(E, **i32)
-    scratch = torch.empty(2 * T, **i32)
+    scratch = torch.empty(2 * T + 24 * ((T + 511) // 512), **i32)
     call("lmod_moe_gate", ptr(logits), ptr(noise), T, E, k, C, ptr(st.gates), ptr(st.idx1), ptr(st.idx2),
          ptr(st.slot1), ptr(st.slot2), ptr(st.w1), ptr(st.w2), ptr(st.slot_token), ptr(st.slot_w),
          ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(st.slots_used), ptr(scratch))
