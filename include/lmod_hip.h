@@ -156,6 +156,7 @@ int lmod_moe_gate_bwd(const float* gates, const int* idx1, const int* idx2, cons
                       int T, int E, int k, hipStream_t stream);
 int lmod_moe_dispatch_bwd(const void* d_in, const int* slot1, const int* slot2, const float* dlogits, const float* wg,
                           void* dx, int T, int H, int E, hipStream_t stream);
+/* dwg[E,H] (+)= dlogits^T x (fp32 router weight gradient).  workspace: ceil(T/64) * E * H floats.  H % 8 == 0. */
 int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float* workspace, int T, int H, int E,
                           int accumulate, hipStream_t stream);
 

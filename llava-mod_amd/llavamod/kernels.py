@@ -315,7 +315,7 @@ def moe_dispatch_bwd(d_in, st, dlogits, wg, H):
 def moe_router_wgrad(x, dlogits, dwg, accumulate):
     T, H = x.shape
     E = dlogits.shape[1]
-    ws = torch.empty(((T + 255) // 256) * E * H, device=x.device, dtype=torch.float32)
+    ws = torch.empty(((T + 63) // 64) * E * H, device=x.device, dtype=torch.float32)      # one partial per 64-token slab
     call("lmod_moe_router_wgrad", ptr(x), ptr(dlogits), ptr(dwg), ptr(ws), T, H, E, int(accumulate))
     return dwg
 
