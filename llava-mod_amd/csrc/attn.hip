@@ -337,25 +337,32 @@ __global__ __launch_bounds__(NTHR, 2) void attn_fwd_kernel(AttnP p) {
 }
 
 // ============================================================================ backward: delta = rowsum(dO * O)
+// 16 lanes per (token, head): 4 pairs per wave (one pair per wave left 48 of 64 lanes idle at hd 128)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                         float* __restrict__ delta, int B, int S, int nh, int HD,
                                                         int lddo, int ldo) {
-  const int lane = threadIdx.x & 63;
-  const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, s, h)
+  const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
+  const long long id = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;   // (b, s, h)
   const long long total = (long long)B * S * nh;
-  if (id >= total) return;
-  const int h = (int)(id % nh);
-  const long long tok = id / nh;
-  const int b = (int)(tok / S), s = (int)(tok % S);
   float a = 0.f;
-  for (int cidx = lane; cidx < (HD >> 3); cidx += 64) {
-    const u32x4 x = *(const u32x4*)(dO + tok * lddo + h * HD + cidx * 8);
-    const u32x4 y = *(const u32x4*)(O + tok * ldo + h * HD + cidx * 8);
+  long long tok = 0; int h = 0;
+  const bool live = id < total;
+  if (live) {
+    h = (int)(id % nh);
+    tok = id / nh;
+    for (int cidx = c; cidx < (HD >> 3); cidx += 16) {
+      const u32x4 x = *(const u32x4*)(dO + tok * lddo + h * HD + cidx * 8);
+      const u32x4 y = *(const u32x4*)(O + tok * ldo + h * HD + cidx * 8);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a += bflo(x[k]) * bflo(y[k]) + bfhi(x[k]) * bfhi(y[k]);
+      for (int k = 0; k < 4; ++k) a += bflo(x[k]) * bflo(y[k]) + bfhi(x[k]) * bfhi(y[k]);
+    }
   }
-  a = wave_sum(a);
-  if (lane == 0) delta[((long long)b * nh + h) * S + s] = a;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (live && c == 0) {
+    const int b = (int)(tok / S), sidx = (int)(tok % S);
+    delta[((long long)b * nh + h) * S + sidx] = a;
+  }
 }
 
 // ============================================================================ backward: dQ
@@ -694,7 +701,7 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale;
   const long long rows = (long long)B * S * nh;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dO,
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo);
   constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;
   const int nqb = (S + QB - 1) / QB, nkb = (S + KBLK - 1) / KBLK;
