@@ -621,29 +621,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int row = row0 + wr * 128 + mt * 16 + li;
-    if (MODE == 0 && p.act == 3) {
-      // fused SwiGLU backward (lmod_gemm_swiglu_bwd_bf16): the accumulators are d(act); with the saved [gate | up]
-      // pre-activations (C2) the epilogue writes [dgate | dup] — d(act) never goes to HBM.  N % 16 == 0 (host-checked).
-      if (cb >= p.N || row >= min((Mv + 7) & ~7, p.M)) continue;
-      bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
-      if (row >= Mv) {           // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
-        continue;
-      }
-      const bf16_t* gp = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + (long long)row * p.ldc2 + cb;
-#pragma unroll
-      for (int hx = 0; hx < 2; ++hx) {
-        float d8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d8[e] = acc[mt][hx * 2 + (e >> 2)][e & 3];
-        u32x4 og, ou;
-        swiglu_bwd8(d8, *(const u32x4*)(gp + hx * 8), *(const u32x4*)(gp + p.N + hx * 8), og, ou);
-        *(u32x4*)(op + hx * 8) = og;
-        *(u32x4*)(op + p.N + hx * 8) = ou;
-      }
-      continue;
-    }
     if (row >= Mv) continue;
     float v[16];
 #pragma unroll
@@ -1139,10 +1116,11 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 }
 
 // Which 256x256 kernel runs a launch.  Measured INSIDE the training step (rocprofv3, per launch grid) the 8-wave kernel
-// is the faster one for plain / fused-SwiGLU-forward / weight-gradient launches (cold operands: it keeps three half
-// tiles in flight and two waves per SIMD), while the 4-wave kernel wins where the epilogue is heavy (fused SwiGLU
-// backward: -15...-20 %) and in back-to-back microbenchmarks with Infinity-Cache-resident operands (+18 % sustained).
-// LMOD_GEMM_WAVES=8 / 4 force one kernel everywhere (A/B runs).
+// is the faster one for plain / fused-SwiGLU-forward / weight-gradient launches (1390-1410 TF at the teacher QKV shape
+// against the 4-wave kernel's ~1270); the fused SwiGLU-backward epilogue lives ONLY in the 4-wave kernel: putting that
+// block into gemm_256_kernel<0>'s epilogue cost the plain GEMM 22 % (1390 -> 1075 TF, found by bisecting library builds
+// in one process, tools/gemm_ab.py) although its main loop compiles to the same instructions.
+// LMOD_GEMM_WAVES=8 / 4 force one kernel where both exist (A/B runs).
 static int gemm_waves() {
   static int w = -1;
   if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4) w = 0; }
@@ -1151,7 +1129,7 @@ static int gemm_waves() {
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   const int w = gemm_waves();
-  const bool four = (w == 4) || (w == 0 && MODE == 0 && p.act == 3);
+  const bool four = (w == 4) || (MODE == 0 && p.act == 3);      // the SwiGLU-backward epilogue only exists in gemm4_kernel
   if (four) {
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G4_STAGE);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
