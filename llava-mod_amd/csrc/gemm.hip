@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       if constexpr (BK) {
         const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
         voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
-      } else if (MODE == 0) {
+      } else if (MODE == 0 || MODE == 4) {
         const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       } else {       // half h = gate (0) / up (1) rows of the same 128 output columns
@@ -603,6 +603,36 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       }
     }
     if (!(SPLIT_OK && p.splitk > 1)) return;
+  }
+  if constexpr (MODE == 4) {
+    // fused SwiGLU backward (lmod_gemm_swiglu_bwd_bf16) as its OWN instantiation: the accumulators are d(act); with the
+    // saved [gate | up] pre-activations (C2) the epilogue writes [dgate | dup].  (Inside the MODE 0 epilogue this block
+    // cost the plain GEMM 22 %.)  N % 16 == 0 (host-checked).
+    const int cb = col0 + wc * 64 + g * 16;
+    const int Mz = min((Mv + 7) & ~7, p.M);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = row0 + wr * 128 + mt * 16 + li;
+      if (cb >= p.N || row >= Mz) continue;
+      bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
+      if (row >= Mv) {           // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
+        continue;
+      }
+      const bf16_t* gp = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + (long long)row * p.ldc2 + cb;
+#pragma unroll
+      for (int hx = 0; hx < 2; ++hx) {
+        float d8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d8[e] = acc[mt][hx * 2 + (e >> 2)][e & 3];
+        u32x4 og, ou;
+        swiglu_bwd8(d8, *(const u32x4*)(gp + hx * 8), *(const u32x4*)(gp + p.N + hx * 8), og, ou);
+        *(u32x4*)(op + hx * 8) = og;
+        *(u32x4*)(op + p.N + hx * 8) = ou;
+      }
+    }
+    return;
   }
   if constexpr (!BK) {
   const int cb = col0 + wc * 64 + g * 16;
@@ -1115,12 +1145,11 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   for (int j = 0; j < 8; ++j) *(u32x4*)(op + (long long)(c0 + j) * ld_out + r0) = b[j];
 }
 
-// Which 256x256 kernel runs a launch.  Measured INSIDE the training step (rocprofv3, per launch grid) the 8-wave kernel
-// is the faster one for plain / fused-SwiGLU-forward / weight-gradient launches (1390-1410 TF at the teacher QKV shape
-// against the 4-wave kernel's ~1270); the fused SwiGLU-backward epilogue lives ONLY in the 4-wave kernel: putting that
-// block into gemm_256_kernel<0>'s epilogue cost the plain GEMM 22 % (1390 -> 1075 TF, found by bisecting library builds
-// in one process, tools/gemm_ab.py) although its main loop compiles to the same instructions.
-// LMOD_GEMM_WAVES=8 / 4 force one kernel where both exist (A/B runs).
+// Which 256x256 kernel runs a launch.  The 8-wave kernel is the default everywhere: 1390-1410 TF at the teacher QKV shape
+// against the 4-wave kernel's ~1270, and the fused SwiGLU backward is 7-13 % faster as its own 8-wave instantiation
+// (MODE 4) than on the 4-wave kernel.  That epilogue must NOT sit inside gemm_256_kernel<0>: there it cost the plain GEMM
+// 22 % (1390 -> 1075 TF, found by timing library builds of three commits in one process, tools/gemm_ab.py).
+// LMOD_GEMM_WAVES=4 runs the 4-wave kernel everywhere (A/B runs).
 static int gemm_waves() {
   static int w = -1;
   if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4) w = 0; }
@@ -1129,10 +1158,12 @@ static int gemm_waves() {
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   const int w = gemm_waves();
-  const bool four = (w == 4) || (MODE == 0 && p.act == 3);      // the SwiGLU-backward epilogue only exists in gemm4_kernel
-  if (four) {
+  if (w == 4) {
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G4_STAGE);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    hipLaunchKernelGGL(gemm_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   } else {
     (void)hipFuncSetAttribute((const void*)gemm_256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
     hipLaunchKernelGGL(gemm_256_kernel<MODE>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
