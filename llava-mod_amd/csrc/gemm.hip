@@ -1155,17 +1155,22 @@ static int gemm_waves() {
   if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4) w = 0; }
   return w;
 }
+template <typename KT>
+static void allow_lds(KT kern, int bytes, bool& done) {      // once per kernel instance, not once per launch
+  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done = true; }
+}
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
+  static bool a4 = false, a8 = false, a84 = false;
   const int w = gemm_waves();
   if (w == 4) {
-    (void)hipFuncSetAttribute((const void*)gemm4_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G4_STAGE);
+    allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
-    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    allow_lds(gemm_256_kernel<4>, 8 * G256_SLOT, a84);
     hipLaunchKernelGGL(gemm_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   } else {
-    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
+    allow_lds(gemm_256_kernel<MODE>, 8 * G256_SLOT, a8);
     hipLaunchKernelGGL(gemm_256_kernel<MODE>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   }
 }
@@ -1277,7 +1282,6 @@ int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, voi
   p.m_valid = m_valid; p.k_valid = nullptr;
   p.act = 3; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
   p.C2 = (void*)gu; p.ldc2 = ld_gu; p.sC2 = stride_gu; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
-  (void)hipFuncSetAttribute((const void*)gemm_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G256_SLOT);
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
