@@ -23,30 +23,8 @@
 // Staging: tiles go global -> registers -> LDS (loads issued before a tile's MFMAs, ds_writes after them,
 // double-buffered LDS, one barrier per tile).  LDS-DMA is not used here: hipcc drains vmcnt(0) before any
 // ds_read while an LDS-DMA is in flight, which serialises load and compute.
-#include "common.h"
-
-#ifndef NWAVE
-#define NWAVE 8
-#endif
-#define NTHR (NWAVE * 64)
-#ifndef ATT_SCHED
-#define ATT_SCHED 1
-#endif
-#ifndef ATT_PRIO
-#define ATT_PRIO 1
-#endif
-
-struct AttnP {
-  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
-  const bf16_t* dO; const float* Delta; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
-  const int* seqlens;
-  int B, S, nh, group;           // group = nh / nkv
-  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-  float scale;
-};
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-template <bool V> struct BoolTag { static constexpr bool value = V; };
+#include "attn_common.h"
+#include <stdlib.h>
 
 // ---- LDS tile image: [rows = tokens][HD bf16], 16-byte chunks XOR-swizzled per row.  Swizzles for HD 128:
 //  SW 0  key = row & 15                      conflict-free for ds_read_b128 operand reads (rows = lane&15);
@@ -672,6 +650,9 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = lse;
   p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
+  static int fwd_ver = -1;         // LMOD_ATTN_FWD=1: the round-1 16x16x32 kernel for hd 128 as well (A/B runs)
+  if (fwd_ver < 0) { const char* e = getenv("LMOD_ATTN_FWD"); fwd_ver = e ? atoi(e) : 2; }
+  if (hd == 128 && fwd_ver != 1) { lmod_launch_attn_fwd2(p, causal, stream); return lmod_launch_status(); }
   constexpr int QB = NWAVE * 32;
   const int nqb = (S + QB - 1) / QB;
   const dim3 grid(causal ? (nqb + 1) / 2 : nqb, nh, B);

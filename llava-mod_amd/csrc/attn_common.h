@@ -1,0 +1,32 @@
+// Shared declarations of the attention kernels (attn.hip: hd 64 + backward; attn_fwd2.hip: hd 128 forward).
+#pragma once
+#include "common.h"
+
+#ifndef NWAVE
+#define NWAVE 8
+#endif
+#define NTHR (NWAVE * 64)
+#ifndef ATT_SCHED
+#define ATT_SCHED 1
+#endif
+#ifndef ATT_PRIO
+#define ATT_PRIO 1
+#endif
+
+struct AttnP {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
+  const bf16_t* dO; const float* Delta; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+  const int* seqlens;
+  int B, S, nh, group;           // group = nh / nkv
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  float scale;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// hd-128 forward, 32x32x16-MFMA software-pipelined kernel (attn_fwd2.hip)
+void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream);

@@ -77,3 +77,32 @@ def test_product_path_never_touches_the_oracle_or_the_reference():
             if re.match(r"\s*(from|import)\s+oracle\b", line):
                 enclosing = next((l for l in reversed(lines[:i]) if re.match(r"def \w+", l)), "")
                 assert enclosing.startswith(f"def {allowed}"), (name, i + 1, enclosing)
+
+
+def test_asm_owned_accumulators_are_not_touched_by_the_compiler(tmp_path):
+    """attn_fwd2.hip keeps its O^T accumulators in a[0:63] through inline asm only (see the file header).  Audit the ISA
+    hipcc emits for it: no spills, exactly the 64 accumulator registers the asm names, and no instruction outside an asm
+    statement that references an accumulator register."""
+    import re
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "llava-mod_amd", "csrc")
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    env = dict(os.environ, KEEP_ISA=str(tmp_path / "fwd2.s"))
+    env["PATH"] = "/opt/rocm/bin:" + env.get("PATH", "")
+    subprocess.run([os.path.join(csrc, "hipcc_agpr.sh"), os.path.join(csrc, "attn_fwd2.hip"), str(tmp_path / "fwd2.o"), "64"],
+                   check=True, env=env)
+    isa = open(tmp_path / "fwd2.s").read()
+    assert re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa) == ["0", "0"]
+    assert re.findall(r"\.private_segment_fixed_size:\s+(\d+)", isa) == ["0", "0"]
+    assert re.findall(r"\.agpr_count:\s+(\d+)", isa) == ["64", "64"]
+    in_asm, bad = False, []
+    for line in isa.split("\n"):
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif not in_asm and not line.lstrip().startswith((";", ".")) and re.search(r"(^|[\s,\[])a(\d+|\[\d+:\d+\])", line):
+            bad.append(line.strip())
+    assert not bad, bad[:5]

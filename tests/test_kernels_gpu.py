@@ -416,6 +416,9 @@ def _attn_ref(q, k, v, scale, causal, seqlens):
     (1, 577, 4, 4, 64, False, False),
     (2, 96, 2, 2, 64, True, True),
     (1, 2048, 2, 2, 128, True, False),
+    (2, 300, 2, 1, 128, False, True),          # hd-128 forward kernel: non-causal, ragged keys, S % 32 != 0, GQA
+    (1, 1000, 3, 3, 128, True, False),         # S % 64 != 0, several query blocks, odd head count
+    (2, 77, 2, 2, 128, False, False),          # shorter than one query block
 ])
 def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
     ld = (nh + 2 * nkv) * hd
@@ -455,6 +458,36 @@ def test_attn_online_softmax_rescale_branch():
                            v.float().reshape(B, S, nh, hd), 1 / math.sqrt(hd), True, None)
     close(o.reshape(B, S, nh, hd), oref, "attn spike", rtol=2 ** -6, afrac=2 ** -7)
     close(lse, lref, "attn spike lse", rtol=1e-3, afrac=1e-3)
+
+
+def test_attn_fwd_hd128_edge_cases():
+    """The 32x32x16 forward kernel (attn_fwd2.hip): a sample with NO visible key (seqlens 0) must give zeros / lse = -inf,
+    a spike well above the deferred-rescale threshold late in the sequence must rescale correctly for every row of the wave,
+    and a max that creeps up by less than the threshold per tile (deferred all the way) must still be exact."""
+    B, S, nh, hd = 2, 320, 2, 128
+    qkv = rnd(B * S, 3 * nh * hd, seed=11)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:2 * nh * hd], qkv[:, 2 * nh * hd:]
+    sl = torch.tensor([0, 200], dtype=torch.int32, device=DEV)
+    o, lse = K.attn_fwd(q, k, v, B, S, nh, nh, hd, 1 / math.sqrt(hd), True, sl)
+    assert o.reshape(B, S, nh * hd)[0].abs().max().item() == 0 and torch.isinf(lse[0]).all() and (lse[0] < 0).all()
+    oref, lref = _attn_ref(q.float().reshape(B, S, nh, hd)[1:], k.float().reshape(B, S, nh, hd)[1:],
+                           v.float().reshape(B, S, nh, hd)[1:], 1 / math.sqrt(hd), True, sl[1:])
+    close(o.reshape(B, S, nh, hd)[1:], oref, "attn len0/len200", rtol=2 ** -6, afrac=2 ** -7)
+    close(lse[1:], lref, "attn len0/len200 lse", rtol=1e-3, afrac=1e-3)
+    # creeping max: key t's score for every query grows by ~1.5 (log2 units ~2.2 < threshold 6) per 64-key tile
+    B, S, nh = 1, 1024, 1
+    g = torch.Generator().manual_seed(5)
+    qv = torch.randn(hd, generator=g)
+    qv = qv / qv.norm()
+    q = (qv[None, :] * math.sqrt(hd) + 0.05 * torch.randn(S, hd, generator=g)).to(BF).to(DEV)
+    kk = (qv[None, :] * (torch.arange(S)[:, None] // 64).float() * 1.5 + 0.05 * torch.randn(S, hd, generator=g)).to(BF).to(DEV)
+    vv = rnd(S, hd, seed=6)
+    for causal in (True, False):
+        o, lse = K.attn_fwd(q, kk, vv, B, S, nh, nh, hd, 1 / math.sqrt(hd), causal)
+        oref, lref = _attn_ref(q.float().reshape(B, S, nh, hd), kk.float().reshape(B, S, nh, hd),
+                               vv.float().reshape(B, S, nh, hd), 1 / math.sqrt(hd), causal, None)
+        close(o.reshape(B, S, nh, hd), oref, f"attn creeping max causal={causal}", rtol=2 ** -6, afrac=2 ** -7)
+        close(lse, lref, "attn creeping max lse", rtol=1e-3, afrac=1e-3)
 
 
 # ------------------------------------------------------------------------------------------ MoE
