@@ -99,39 +99,87 @@ def executed_tflop_per_sample(S=2048, rows=513):
     return mimic_tflop(head_rows=rows) - (t_last + s_last) / 1e12
 
 
-def cpu_baseline():
-    """The oracle (fp32 PyTorch restatement, oracle/) timed on this box's host cores on a BOUNDED,
-    depth-reduced sample of the same workload (config-2 widths, B=1, S=2048), scaled to full depth by
-    algorithmic FLOPs.  A reported baseline, not a target."""
+def _mem_total_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal:"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto"):
+    """The oracle (fp32 PyTorch restatement of the reference, oracle/) timed on this box's host cores on ONE sample of the
+    same workload (config 2, B=1, S=2048): teacher forward + student forward/backward + losses (no optimizer step).
+
+    mode "full" (auto: host RAM >= 96 GB): FULL depth — 32-layer 7B teacher, 24-layer MoE student, 23 ViT
+    layers — carrying the very weights of the GPU models; the same batch is then run through the GPU path (routing noise off
+    on both sides) and the four logged loss scalars are compared: `loss_delta`.
+    mode "sample": depth-reduced (2 + 2 decoder layers, 2 ViT layers, full-vocabulary heads), scaled to the full-depth
+    sample by algorithmic FLOPs; used when the host is too small, and said so.  A reported baseline, not a target."""
     from oracle.decoder import DecoderConfig
-    from oracle.llava import LlavaOracle, freeze_like_d2s, mimic_step
+    from oracle.llava import LlavaOracle, freeze_like_d2s, load_from_product_state, mimic_step
     from oracle.vision import VisionConfig
     cores = min(os.cpu_count() or 1, 128)
     torch.set_num_threads(cores)
     V = 151936
-    vit_l, t_l = 2, 2
+    mem = _mem_total_gb()
+    full = (mode == "full") or (mode == "auto" and mem >= 96 and student is not None)
+    vit_l, t_l, s_l = (23, 32, 24) if full else (2, 2, 2)
     vc = VisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=vit_l + 1, num_attention_heads=16,
                       image_size=336, patch_size=14, select_layer=-2)
-    sc = DecoderConfig(vocab_size=V, hidden_size=2048, intermediate_size=5504, num_hidden_layers=2,
-                       num_attention_heads=16, num_key_value_heads=16, moe_layers_idx=[0], num_experts=4, top_k_experts=2,
-                       capacity_factor=1.5, min_capacity=0, max_position_embeddings=2048)
+    sc = DecoderConfig(vocab_size=V, hidden_size=2048, intermediate_size=5504, num_hidden_layers=s_l,
+                       num_attention_heads=16, num_key_value_heads=16, moe_layers_idx=list(range(0, s_l, 2)), num_experts=4,
+                       top_k_experts=2, capacity_factor=1.5, min_capacity=0, max_position_embeddings=4096,
+                       rope_theta=1000000.0)
     tc = DecoderConfig(vocab_size=V, hidden_size=4096, intermediate_size=11008, num_hidden_layers=t_l,
-                       num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=2048)
-    student, teacher = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
-    freeze_like_d2s(student)
+                       num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=4096, rope_theta=1000000.0)
     b = synthetic_batch(1, 3)
-    b["images"] = b["images"].float()
-    student.train(); teacher.eval()
+    loss_delta = None
+    if full:
+        with torch.device("meta"):                             # no host-side random init of 10.7 B parameters
+            o_student, o_teacher = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
+        o_student.to_empty(device="cpu"); o_teacher.to_empty(device="cpu")
+        load_from_product_state(o_student, student.state_dict())
+        load_from_product_state(o_teacher, teacher.state_dict())
+    else:
+        o_student, o_teacher = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
+    freeze_like_d2s(o_student)
+    cb = dict(b, images=b["images"].float())
+    o_student.train(); o_teacher.eval()
+    o_student.set_gate_noise(None)
     t0 = time.time()
-    mimic_step(student, teacher, b, loss_type="kd_lm")
-    t_red = time.time() - t0
-    tf_red = mimic_tflop(t_layers=t_l, s_dense=1, s_moe=1, vit_layers=vit_l)
-    rate = tf_red / t_red
-    return {"value": round(rate / TFLOP_PER_SAMPLE_LEDGER, 5), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 torch-CPU mimic step (teacher fwd + student fwd/bwd + losses), B=1 S=2048, config-2 "
-                      f"widths, depth-reduced to teacher {t_l}/32, student 2/24 (1 dense + 1 MoE), ViT {vit_l}/23 layers, "
-                      f"full-vocab heads: {tf_red:.2f} algorithmic TFLOP in {t_red:.1f} s = {rate:.2f} TFLOP/s; "
-                      f"scaled to the 52.98 TFLOP full-depth sample"}
+    _, logs, _, _ = mimic_step(o_student, o_teacher, cb, loss_type="kd_lm")
+    t_cpu = time.time() - t0
+    tf = mimic_tflop(t_layers=t_l, s_dense=s_l // 2, s_moe=s_l // 2, vit_layers=vit_l)
+    rate = tf / t_cpu
+    if full:
+        moes = student.moe_layers()
+        old = [(m.deterministic, m.gate_noise) for m in moes]
+        for m in moes:
+            m.deterministic, m.gate_noise = True, None
+        with torch.no_grad():
+            _, outs = trainer.compute_loss(student, b, return_outputs=True)
+        for m, (d, n) in zip(moes, old):
+            m.deterministic, m.gate_noise = d, n
+        loss_delta = {}
+        for k in ("loss", "loss/align", "loss/lm", "loss/moe_balance"):
+            g, c = float(outs[k].detach()), float(logs[k].detach())
+            loss_delta[k] = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "rel": round(abs(g - c) / max(abs(c), 1e-30), 6)}
+        sample = (f"oracle fp32 torch-CPU mimic step at FULL depth (32-layer teacher fwd + 24-layer MoE student fwd/bwd + "
+                  f"23-layer ViT x2 + losses; no optimizer), B=1 S=2048, same weights and batch as the GPU models "
+                  f"(host RAM {mem:.0f} GB): {tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s")
+        value = 1.0 / t_cpu
+    else:
+        sample = (f"oracle fp32 torch-CPU mimic step, B=1 S=2048, config-2 widths, DEPTH-REDUCED (host RAM {mem:.0f} GB < 96 GB "
+                  f"or --cpu-baseline sample) to teacher {t_l}/32, student {s_l}/24, ViT {vit_l}/23 layers, full-vocab heads: "
+                  f"{tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s; scaled to the 52.98 TFLOP full-depth sample")
+        value = rate / TFLOP_PER_SAMPLE_LEDGER
+    out = {"value": round(value, 5), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
+    if loss_delta is not None:
+        out["loss_delta"] = loss_delta
+    return out
 
 
 def main():
@@ -140,8 +188,17 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--grad-accum", type=int, default=2,
+                    help="micro-batches per optimizer step (reference regime: --gradient_accumulation_steps, "
+                         "dense2sparse_distillation.sh:70-72); 16 x 2 per GPU = global batch 256 on 8 GPUs (config 3)")
+    ap.add_argument("--no-zero2", action="store_true",
+                    help="N>1: all-reduce + full optimizer on every rank instead of reduce-scatter / sharded AdamW / all-gather")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient exchange (N>1)")
+    ap.add_argument("--max-grad-norm", type=float, default=1.0, help="global-norm clipping (HF Trainer default 1.0); 0 = off")
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
+                    help="auto: full-depth oracle step (same weights, loss compared with the GPU) when host RAM >= 96 GB")
     ap.add_argument("--optimizer-overlap", action="store_true",
                     help="just-in-time AdamW on a second stream (bit-identical; measured 0.3 %% slower than serial, off by default)")
     ap.add_argument("--separate-towers", action="store_true", help="different random CLIP towers: both are run (no feature sharing)")
@@ -173,17 +230,19 @@ def main():
     student.train(); teacher.eval()
     n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
     gb = GradBuffer(student)
-    opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0)
-    dp = DataParallel().attach(gb, args.ep)
+    dp = DataParallel(zero2=not args.no_zero2, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
+                      ).attach(gb, args.ep)
+    opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0, dp=dp, max_grad_norm=args.max_grad_norm or None)
+    A = args.grad_accum
     if args.stage == "mimic":
         trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
                                                                         loss_type="kd_lm", moe_loss_enable=True))())
-        batches = [synthetic_batch(B, 1000 * rank + i) for i in range(2)]
+        batches = [synthetic_batch(B, 1000 * rank + i) for i in range(max(2, A))]
     else:       # config 4: chosen / rejected pairs sharing the image; kto_pair is the shell default (preference_distillation.sh:29)
         from llavamod.train.dpo_trainer import DPOTrainer
         trainer = DPOTrainer(student, teacher, beta=0.1, loss_type="kto_pair")
         batches = []
-        for i in range(2):
+        for i in range(max(2, A)):
             ch, rj = synthetic_batch(B, 1000 * rank + i), synthetic_batch(B, 5000 + 1000 * rank + i)
             batches.append(dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"],
                                 chosen_attention_mask=ch["attention_mask"], rejected_input_ids=rj["input_ids"],
@@ -199,17 +258,25 @@ def main():
     prefetch = trainer.prefetch_teacher if args.stage == "mimic" else trainer.prefetch_reference
     state = {"teacher": prefetch(batches[0]) if pipelined else None}
 
+    nb = len(batches)
+
     def step(i):
+        """One optimizer step = A micro-batches (gradients accumulate in the fp32 buffer; the exchange is armed on the
+        last one only) + gradient exchange + clipping + AdamW."""
         gb.zero()
-        if pipelined:
-            nxt = prefetch(batches[(i + 1) % 2])
-            kw = {"teacher" if args.stage == "mimic" else "reference": state["teacher"]}
-            loss = trainer.training_step(student, batches[i % 2], **kw)
-            state["teacher"] = nxt
-        else:
-            loss = trainer.training_step(student, batches[i % 2])
-        dp.finish()                      # spans were all-reduced asynchronously as backward produced them
-        opt.step(grad_scale=1.0 / world, lr=warmup_cosine(i, max(total, 100), 2e-5), overlap=args.optimizer_overlap,
+        for a in range(A):
+            k = i * A + a
+            dp.armed = (a == A - 1)
+            if pipelined:
+                nxt = prefetch(batches[(k + 1) % nb])
+                kw = {"teacher" if args.stage == "mimic" else "reference": state["teacher"]}
+                loss = trainer.training_step(student, batches[k % nb], **kw)
+                state["teacher"] = nxt
+            else:
+                loss = trainer.training_step(student, batches[k % nb])
+        dp.finish()                      # spans were exchanged asynchronously as the last backward produced them
+        # the reference averages the loss over the accumulation window and the ranks: fold both means into the scale
+        opt.step(grad_scale=1.0 / (world * A), lr=warmup_cosine(i, max(total, 100), 2e-5), overlap=args.optimizer_overlap,
                  clear_grads=True)          # gradients are cleared inside the AdamW pass: no separate 8 GB memset
         return loss
 
@@ -239,7 +306,7 @@ def main():
     loss_val = float(last)
 
     if rank == 0:
-        sps = args.steps * B * world / dt
+        sps = args.steps * B * A * world / dt
         ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
         achieved = ledger * sps / world
         # dominant kernel (gemm_256_kernel<0>, ~51 % of GPU time in profiles/) at the shape it spends most time on —
@@ -276,9 +343,13 @@ def main():
                                     "config 4: preference distillation (kto_pair), value = chosen/rejected PAIRS per second") +
                                    f", CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({args.experts} experts, top-2, cf 1.5, 12 MoE layers, "
                                    f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
-                       "micro_batch_per_gpu": B, "global_batch": B * world, "seq_len": 2048, "response_tokens": 512,
-                       "parallelism": f"dp{world}", "optimizer": "fused AdamW every step (fp32 master)" + ("" if not args.optimizer_overlap else
-                                    ", just-in-time: spans updated on a second stream in forward order, gradients cleared in the same pass"),
+                       "micro_batch_per_gpu": B, "grad_accum": A, "global_batch": B * A * world, "seq_len": 2048,
+                       "response_tokens": 512, "parallelism": f"dp{world}",
+                       "optimizer": ("fused AdamW once per step (fp32 master), global-norm clipping "
+                                     f"{args.max_grad_norm if args.max_grad_norm else 'off'}" +
+                                     (f", ZeRO-2 style: {args.grad_dtype} reduce-scatter -> sharded AdamW -> bf16 all-gather"
+                                      if (world > 1 and not args.no_zero2) else (", fp32 all-reduce" if world > 1 else "")) +
+                                     ("" if not args.optimizer_overlap else ", just-in-time on a second stream")),
                        "image_tower": ("different weights per model, run twice" if args.separate_towers or args.stage != "mimic" else
                                        "student and teacher towers bit-identical (same checkpoint): features computed once per batch, shared"),
                        "teacher_pipelining": ("teacher fwd of batch i+1 on a side stream under the student's step i (student on a "
@@ -296,7 +367,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer if args.stage == "mimic" else None,
+                                                   args.cpu_baseline if args.stage == "mimic" else "sample")
             except Exception as e:                              # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(out), flush=True)

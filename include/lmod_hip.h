@@ -119,10 +119,20 @@ int lmod_vit_embed(const void* patch_emb, const void* cls, const void* pos, void
                    hipStream_t stream);
 /* torch.optim.AdamW step (HF `adamw_torch`, config/args.py:78) on fp32 master weights with a bf16
  * working copy; grad is fp32, scaled by grad_scale first.  zero_grad != 0: the gradient is cleared in the same pass
- * (the optimizer's zero_grad(), without a separate memset of the gradient buffer). */
+ * (the optimizer's zero_grad(), without a separate memset of the gradient buffer).  dev_scale (nullable): one fp32 on
+ * the device that multiplies grad_scale — the gradient-clipping coefficient of lmod_clip_coef, read without a host sync. */
 int lmod_adamw_step(float* master, void* param_bf16, float* grad, float* m, float* v, long long n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad,
-                    hipStream_t stream);
+                    const float* dev_scale, hipStream_t stream);
+/* Global gradient-norm clipping (HF Trainer max_grad_norm = 1.0 under DeepSpeed `"gradient_clipping": "auto"`,
+ * config/dpconfig/zero2_offload.json; torch.nn.utils.clip_grad_norm_ arithmetic).
+ * lmod_sumsq_f32: out[0] (+)= sum(x[i]^2), deterministic (fixed reduction order); partials: >= 1024 floats of scratch.
+ * lmod_clip_coef: coef[0] = min(1, max_norm / (sqrt(sumsq[0]) * norm_scale + 1e-6)); norm_out (nullable) gets the norm. */
+int lmod_sumsq_f32(const float* x, long long n, float* partials, float* out, int accumulate, hipStream_t stream);
+int lmod_clip_coef(const float* sumsq, float norm_scale, float max_norm, float* coef, float* norm_out, hipStream_t stream);
+/* fp32 <-> bf16 (round to nearest even) over n elements: gradients are exchanged in bf16 like the reference's bf16
+ * engine (DeepSpeed bf16 + ZeRO-2 reduce-scatters bf16 gradients). */
+int lmod_cast_f32_bf16(const void* src, void* dst, long long n, int to_bf16, hipStream_t stream);
 
 /* ---- attention -------------------------------------------------------------------------------
  * softmax(Q K^T * scale + mask) V with causal and right-padding masks, GQA (nh % nkv == 0).

@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, bf16_t* __restrict__ param,
                                                    float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2, float gscale, int zero_grad) {
+                                                   float eps, float wd, float bc1, float bc2, float gscale, int zero_grad,
+                                                   const float* __restrict__ dev_scale) {
+  if (dev_scale) gscale *= dev_scale[0];     // gradient-clipping coefficient computed on the device (no host sync)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float g = grad[i] * gscale;
     if (zero_grad) grad[i] = 0.f;            // the gradient buffer is consumed: no separate memset before the next step
@@ -398,6 +400,59 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     master[i] = p;
     param[i] = f2bf(p);
   }
+}
+
+// Global gradient norm for clipping (HF Trainer max_grad_norm / DeepSpeed gradient_clipping, reference
+// config/dpconfig/zero2*.json "gradient_clipping": "auto"): deterministic two-stage sum of squares.  Stage 1: SUMSQ_BLOCKS
+// blocks grid-stride over the span, one partial each; stage 2: one block adds the partials in a fixed order into out[0]
+// (accumulating, so several spans chain into one scalar).
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float a = 0.f;
+  // up to 3 leading elements bring the pointer to a 16-byte boundary (block 0), then 16-byte loads, then the tail
+  const int head = (int)min((long long)(((16 - ((uintptr_t)x & 15)) & 15) >> 2), n);
+  if (blockIdx.x == 0 && threadIdx.x < head) { const float t = x[threadIdx.x]; a += t * t; }
+  x += head; n -= head;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x - 64 < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x - 64]; a += t * t; }
+  a = block_sum<4>(a, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) a += part[i];
+  a = block_sum<4>(a, red);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + a : a;
+}
+// coef = min(1, max_norm / (sqrt(sumsq) * norm_scale + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float norm_scale, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+  const float nrm = sqrtf(sumsq[0]) * norm_scale;
+  coef[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+  if (norm_out) norm_out[0] = nrm;
+}
+// fp32 -> bf16 (round to nearest even) and back, for exchanging gradients in bf16 like the reference's bf16 engine
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    *(u32x2*)(y + 4 * i) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = f2bf(x[(n4 << 2) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const u32x2 v = *(const u32x2*)(x + 4 * i);
+    *(f32x4*)(y + 4 * i) = (f32x4){bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = bf2f(x[(n4 << 2) + threadIdx.x]);
 }
 
 static inline int grid_for(long long work, int cap = 256 * 16) {
@@ -523,12 +578,36 @@ int lmod_vit_embed(const void* patch_emb, const void* cls, const void* pos, void
 
 int lmod_adamw_step(float* master, void* param_bf16, float* grad, float* m, float* v, long long n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad,
-                    hipStream_t stream) {
+                    const float* dev_scale, hipStream_t stream) {
   if (!master || !param_bf16 || !grad || !m || !v || n < 0 || step < 1) return LMOD_EINVAL;
   if (n == 0) return LMOD_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, master, (bf16_t*)param_bf16, grad, m, v,
-                     n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, zero_grad);
+                     n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, zero_grad, dev_scale);
+  return lmod_launch_status();
+}
+
+int lmod_sumsq_f32(const float* x, long long n, float* partials, float* out, int accumulate, hipStream_t stream) {
+  if (!partials || !out || n < 0 || (n > 0 && !x)) return LMOD_EINVAL;
+  if (((uintptr_t)x & 3)) return LMOD_EINVAL;
+  const int nb = n == 0 ? 0 : grid_for((n + 3) / 4, SUMSQ_BLOCKS);
+  if (nb) hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, x, n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, nb, out, accumulate);
+  return lmod_launch_status();
+}
+
+int lmod_clip_coef(const float* sumsq, float norm_scale, float max_norm, float* coef, float* norm_out, hipStream_t stream) {
+  if (!sumsq || !coef || !(max_norm > 0.f)) return LMOD_EINVAL;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, norm_scale, max_norm, coef, norm_out);
+  return lmod_launch_status();
+}
+
+int lmod_cast_f32_bf16(const void* src, void* dst, long long n, int to_bf16, hipStream_t stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return LMOD_EINVAL;
+  if (n == 0) return LMOD_OK;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return LMOD_EINVAL;
+  if (to_bf16) hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, (const float*)src, (bf16_t*)dst, n);
+  else hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)src, (float*)dst, n);
   return lmod_launch_status();
 }
 

@@ -32,7 +32,10 @@ SIGNATURES = {
     "lmod_gather_rows": "pppp" + "qi" + "p",
     "lmod_im2col_patch": "pp" + "iiii" + "p",
     "lmod_vit_embed": "pppp" + "iii" + "p",
-    "lmod_adamw_step": "ppppp" + "q" + "fffff" + "i" + "f" + "i" + "p",
+    "lmod_adamw_step": "ppppp" + "q" + "fffff" + "i" + "f" + "i" + "p" + "p",
+    "lmod_sumsq_f32": "pq" + "pp" + "i" + "p",
+    "lmod_clip_coef": "pff" + "pp" + "p",
+    "lmod_cast_f32_bf16": "pp" + "qi" + "p",
     "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
     "lmod_moe_router_fwd": "ppp" + "iii" + "p",

@@ -95,25 +95,30 @@ def load_checkpoint(model, path, strict=True):
     Returns (missing, unexpected)."""
     src = {_normalise(k): v for k, v in read_state(path).items()}
     own = model.state_dict()
-    used, missing = set(), []
-    with torch.no_grad():
-        for k, t in own.items():
-            v = src.get(k)
-            if v is None:
-                m = re.match(r"(.*\.mlp\.)deepspeed_moe\.experts\.deepspeed_experts\.\d+\.(.*)", k)
-                if m and (m.group(1) + m.group(2)) in src:
-                    v = src[m.group(1) + m.group(2)]
-                    used.add(m.group(1) + m.group(2))
-            else:
-                used.add(k)
-            if v is None:
-                missing.append(k)
-                continue
-            if tuple(v.shape) != tuple(t.shape):
-                raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model shape {tuple(t.shape)}")
-            t.copy_(v.to(device=t.device, dtype=t.dtype))
+    used, missing, plan = set(), [], []
+    for k, t in own.items():                 # validate everything BEFORE touching the model: a failed load leaves it intact
+        v = src.get(k)
+        if v is None:
+            m = re.match(r"(.*\.mlp\.)deepspeed_moe\.experts\.deepspeed_experts\.\d+\.(.*)", k)
+            if m and (m.group(1) + m.group(2)) in src:
+                v = src[m.group(1) + m.group(2)]
+                used.add(m.group(1) + m.group(2))
+        else:
+            used.add(k)
+        if v is None:
+            missing.append(k)
+            continue
+        if tuple(v.shape) != tuple(t.shape):
+            raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model shape {tuple(t.shape)}")
+        plan.append((t, v))
     unexpected = sorted(set(src) - used)
     if strict and (missing or unexpected):
         raise KeyError(f"missing {missing[:5]}{'...' if len(missing) > 5 else ''}, "
                        f"unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+    with torch.no_grad():
+        for t, v in plan:
+            t.copy_(v.to(device=t.device, dtype=t.dtype))
+    # weights changed behind the caches' back: fused-weight transposes are keyed on parameter versions (copy_ bumps them);
+    # optimizers holding fp32 masters must be told (HipAdamW.resync_master()); trainers re-check tower sharing
+    model._weights_epoch = getattr(model, "_weights_epoch", 0) + 1
     return missing, unexpected

@@ -87,14 +87,22 @@ class GradBuffer:
         # needed because MoE modules are visited before their expert children in model.modules().
         for n, p in model.named_parameters():
             if p.requires_grad and id(p) not in covered:
+                # norm scales, the embedding table and the CLIP tower have no weight-gradient kernel on this path (the
+                # distillation shells freeze them: dense2sparse_distillation.sh train_modules); fail loudly, not silently
+                if not (n.endswith("wg.weight") or ".wg." in n):
+                    raise NotImplementedError(
+                        f"parameter {n!r} is marked trainable but this path computes no gradient for it (supported: "
+                        f"attention / MLP / expert / projector / lm_head linears and the MoE router); freeze it or list "
+                        f"only supported modules in train_modules")
                 spans.append(("p", p, p.numel()))
                 covered.add(id(p))
         # dense (replicated) parameters first, expert-parallel-sharded expert weights last: two contiguous regions
         is_exp = lambda sp: bool(getattr(sp[1], "is_expert", False)) and sp[0] == "w"
         spans = [sp for sp in spans if not is_exp(sp)] + [sp for sp in spans if is_exp(sp)]
-        self.n_dense = sum(n for sp in spans if not is_exp(sp) for n in [sp[2]])
+        self.n_dense = sum((n + 7) // 8 * 8 for sp in spans if not is_exp(sp) for n in [sp[2]])
         self.spans = spans
-        total = sum(n for _, _, n in spans)
+        al = lambda x: (x + 7) // 8 * 8     # span starts on 8-element boundaries: 16-byte vector access in fp32 and bf16
+        total = sum(al(n) for _, _, n in spans)
         dev = next(model.parameters()).device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         off = 0
@@ -108,8 +116,36 @@ class GradBuffer:
             else:
                 obj.main_grad = view.view(obj.shape)
             self.offsets.append(off)
-            off += n
+            off += al(n)
         self.numel = total
+
+    def flatten_params(self):
+        """Move every bf16 span's working weights into ONE flat bf16 buffer laid out like the gradient buffer (the
+        nn.Parameters stay views of it): the in-place all-gather target of the ZeRO-2 style optimizer."""
+        if getattr(self, "pflat", None) is not None:
+            return self.pflat
+        self.pflat = torch.zeros(self.numel, device=self.flat.device, dtype=BF16)
+        for (kind, obj, n), off in zip(self.spans, self.offsets):
+            view = self.pflat[off:off + n]
+            if kind == "w":
+                new = view.view(obj.w.shape)
+                new.copy_(obj.w)
+                for p, v in obj._views(new):
+                    p.data = v
+                obj.w, obj.wt, obj._wt_version = new, None, None
+            elif kind == "b":
+                new = view.view(obj.b.shape)
+                new.copy_(obj.b)
+                r = 0
+                for bp in obj.bias_groups[0]:
+                    bp.data = new[r:r + bp.shape[0]]
+                    r += bp.shape[0]
+                obj.b = new
+            elif obj.dtype == BF16:
+                new = view.view(obj.shape)
+                new.copy_(obj.data)
+                obj.data = new
+        return self.pflat
 
     def zero(self):
         if getattr(self, "clean", False):        # the optimizer cleared every span in its own pass (HipAdamW overlap)
@@ -122,67 +158,130 @@ class GradBuffer:
 
 
 class DataParallel:
-    """Sample-sharded data parallelism: every rank runs teacher + student on its own micro-batches; the
-    only exchange is the SUM all-reduce of the flat gradient buffer at the optimizer boundary (the
-    division by world size is folded into AdamW's grad scale).  Loss normalisation stays per-rank, as
-    in the reference (align_trainer.py:526 divides by the local mask sum; DeepSpeed then averages).
+    """Sample-sharded data parallelism: every rank runs teacher + student on its own micro-batches; the only exchange is
+    the SUM of the flat gradient buffer at the optimizer boundary (the division by world size is folded into AdamW's grad
+    scale).  Loss normalisation stays per-rank, as in the reference (align_trainer.py:526 divides by the local mask sum;
+    DeepSpeed then averages).
 
-    Overlap: `attach(gb)` hooks every fused weight; as soon as a weight's last wgrad GEMM of the backward
-    has been enqueued its span is all-reduced asynchronously (RCCL runs on its own stream, ordered after
-    the compute stream by an event), so the exchange hides under the rest of backward.  `finish()` reduces
-    whatever has no hook (router weights, biases) and waits.  Expert weights sharded over an expert-
-    parallel group are reduced only over the ranks that hold the same experts."""
+    Two exchange regimes:
+      * all-reduce (zero2=False): every rank ends with the full summed gradient and runs the full optimizer.
+      * ZeRO-2 style (zero2=True; the reference's regime, config/dpconfig/zero2_offload.json): a span is REDUCE-SCATTERED
+        in place — rank r of the span's group ends with the sum of chunk r only — `HipAdamW` updates that chunk of the fp32
+        master / m / v (1/N of the optimizer state and work per rank) and the updated bf16 weights are ALL-GATHERED in
+        place into the flat parameter buffer.  Per optimizer step a rank moves (N-1)/N x (grad bytes + bf16 param bytes)
+        instead of 2 (N-1)/N x grad bytes.  Spans too small or not divisible by the group size stay replicated.
+      grad_dtype=torch.bfloat16 exchanges gradients in bf16 (what the reference's bf16 engine does): the fp32 span is cast
+      into a bf16 staging buffer, reduced there, and the owned chunk cast back.
 
-    def __init__(self, bucket_bytes=512 << 20, overlap=True):
+    Overlap: `attach(gb)` hooks every fused weight; as soon as a weight's last wgrad GEMM of the backward has been enqueued
+    its span is exchanged asynchronously (RCCL runs on its own stream, ordered after the compute stream by an event), so
+    the exchange hides under the rest of backward.  `finish()` sends whatever has no hook (router weights, lone biases)
+    and waits.  Expert weights sharded over an expert-parallel group are reduced only over the ranks that hold the same
+    experts.  `armed=False` (non-final micro-batches of a gradient-accumulation window) defers everything to `finish()`
+    of the final micro-batch."""
+
+    def __init__(self, bucket_bytes=512 << 20, overlap=True, zero2=False, grad_dtype=torch.float32, min_shard_numel=1 << 16):
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.enabled else 1
+        self.rank = dist.get_rank() if self.enabled else 0
         self.bucket = bucket_bytes // 4
         self.overlap = overlap
+        self.zero2 = bool(zero2) and self.enabled
+        self.grad_dtype = grad_dtype
+        self.min_shard = min_shard_numel
         self.armed = True                 # set False on non-final micro-batches of a gradient-accumulation window
-        self._handles, self._done, self._map = [], set(), {}
-        self.gb, self.ep_size = None, 1
+        self._handles, self._done, self._map, self._bias = [], set(), {}, {}   # _done holds (id(obj), kind) of sent spans
+        self._castback = []               # bf16 exchange: (lo, hi) chunks to cast back to fp32 once the collective is done
+        self.gb, self.ep_size, self.plan, self._gbf = None, 1, {}, None
+
+    # ---- layout ----------------------------------------------------------------------------------------------------
+    def _group_of(self, is_expert):
+        """(process group or None for the world, group size, this rank's index in it); None if nothing to exchange."""
+        if is_expert and self.ep_size > 1:
+            gsize = self.world // self.ep_size
+            if gsize <= 1:
+                return None
+            return expert_data_parallel_group(self.ep_size), gsize, self.rank // self.ep_size
+        return None, self.world, self.rank
 
     def attach(self, gb, ep_size=1):
         self.gb, self.ep_size = gb, ep_size
         for (kind, obj, n), off in zip(gb.spans, gb.offsets):
+            is_exp = kind == "w" and bool(getattr(obj, "is_expert", False))
+            grp = self._group_of(is_exp) if self.enabled else None
+            tgt = obj.w if kind == "w" else obj.b if kind == "b" else obj
+            info = dict(off=off, n=n, is_expert=is_exp, group=None, gsize=1, grank=0, sharded=False, lo=off, hi=off + n)
+            if grp is not None:
+                g, gsize, grank = grp
+                sharded = self.zero2 and tgt.dtype == BF16 and n % (8 * gsize) == 0 and n >= self.min_shard   # chunks stay 16-byte aligned
+                info.update(group=g, gsize=gsize, grank=grank, sharded=sharded)
+                if sharded:
+                    c = n // gsize
+                    info.update(lo=off + grank * c, hi=off + (grank + 1) * c)
+            info["exchange"] = grp is not None
+            self.plan[(id(obj), kind)] = info
             if kind == "w":
-                self._map[id(obj)] = (off, n, bool(getattr(obj, "is_expert", False)))
+                self._map[id(obj)] = (off, n, is_exp)
                 obj.grad_ready_hook = self._on_ready
+            elif kind == "b":                 # a fused weight's bias span travels with its weight span (same ready hook)
+                self._bias[id(obj)] = (off, n)
+        if self.zero2:
+            gb.flatten_params()
+        if self.enabled and self.grad_dtype == BF16:
+            self._gbf = torch.empty(gb.numel, device=gb.flat.device, dtype=BF16)
         return self
 
-    def _group_for(self, is_expert):
-        if is_expert and self.ep_size > 1:
-            return expert_data_parallel_group(self.ep_size) if self.world // self.ep_size > 1 else "skip"
-        return None
+    def owned(self, obj, kind):
+        """[lo, hi) of the flat buffers this rank's optimizer updates for the span, and whether it is the rank that
+        counts the span in global reductions (a replicated span is counted once per group)."""
+        info = self.plan.get((id(obj), kind))
+        if info is None:
+            off = self.gb.offsets[[i for i, sp in enumerate(self.gb.spans) if sp[1] is obj and sp[0] == kind][0]]
+            n = [sp[2] for sp in self.gb.spans if sp[1] is obj and sp[0] == kind][0]
+            return off, off + n, True
+        return info["lo"], info["hi"], (info["sharded"] or info["grank"] == 0)
 
-    def _reduce(self, lo, hi, is_expert):
-        g = self._group_for(is_expert)
-        if g == "skip":
+    # ---- exchange --------------------------------------------------------------------------------------------------
+    def _send(self, obj, kind):
+        info = self.plan[(id(obj), kind)]
+        self._done.add((id(obj), kind))
+        if not info["exchange"]:
             return
-        for a in range(lo, hi, self.bucket):
-            self._handles.append(dist.all_reduce(self.gb.flat[a:min(a + self.bucket, hi)], op=dist.ReduceOp.SUM,
-                                                 group=g, async_op=True))
+        off, n, g = info["off"], info["n"], info["group"]
+        flat = self.gb.flat
+        if self.grad_dtype == BF16:
+            K.cast_f32_bf16(flat[off:off + n], self._gbf[off:off + n])
+            flat = self._gbf
+            self._castback.append((info["lo"], info["hi"]))
+        if info["sharded"]:
+            self._handles.append(dist.reduce_scatter_tensor(flat[info["lo"]:info["hi"]], flat[off:off + n],
+                                                            op=dist.ReduceOp.SUM, group=g, async_op=True))
+        else:
+            for a in range(off, off + n, self.bucket):
+                self._handles.append(dist.all_reduce(flat[a:min(a + self.bucket, off + n)], op=dist.ReduceOp.SUM, group=g,
+                                                     async_op=True))
 
     def _on_ready(self, fw):
-        if not (self.enabled and self.overlap and self.armed) or id(fw) in self._done:
+        if not (self.enabled and self.overlap and self.armed) or (id(fw), "w") in self._done:
             return
-        off, n, is_exp = self._map[id(fw)]
-        self._reduce(off, off + n, is_exp)
-        self._done.add(id(fw))
+        self._send(fw, "w")
+        if id(fw) in self._bias:              # linear_wgrad adds the bias gradient before it calls grad_done()
+            self._send(fw, "b")
 
     def finish(self):
-        """Reduce every span that was not already sent by a hook, then wait for all of it."""
-        if self.enabled:
-            for (kind, obj, n), off in zip(self.gb.spans, self.gb.offsets):
-                if id(obj) in self._done:
-                    continue
-                self._reduce(off, off + n, kind == "w" and bool(getattr(obj, "is_expert", False)))
+        """Exchange every span that was not already sent by a hook, then wait for all of it."""
+        if self.enabled and self.armed:
+            for kind, obj, _ in self.gb.spans:
+                if (id(obj), kind) not in self._done:
+                    self._send(obj, kind)
             for h in self._handles:
                 h.wait()
-        self._handles, self._done = [], set()
+            for lo, hi in self._castback:
+                K.cast_f32_bf16(self._gbf[lo:hi], self.gb.flat[lo:hi])
+        self._handles, self._done, self._castback = [], set(), []
 
     def all_reduce(self, flat, n_dense=None, ep_size=1):
-        """Non-overlapped form: SUM over the DP world for the first n_dense elements (replicated parameters);
+        """Non-overlapped all-reduce form: SUM over the DP world for the first n_dense elements (replicated parameters);
         the expert region [n_dense:] is reduced only over the ranks that hold the same experts."""
         if not self.enabled:
             return
@@ -199,75 +298,133 @@ class DataParallel:
 
 
 class HipAdamW:
-    """torch.optim.AdamW arithmetic (HF `adamw_torch`, reference config/args.py:78) as one fused kernel per
-    span: fp32 master / m / v, bf16 working copy refreshed in the same pass."""
+    """torch.optim.AdamW arithmetic (HF `adamw_torch`, reference config/args.py:78) as one fused kernel per span: fp32
+    master / m / v, bf16 working copy refreshed in the same pass.
 
-    def __init__(self, gb: GradBuffer, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.gb = gb
+    dp (a `DataParallel` with zero2=True): optimizer state exists only for the chunks this rank owns after the
+    reduce-scatter; after the update the bf16 chunks are all-gathered in place into `gb.pflat` (ZeRO-2 partitioning,
+    the reference's regime — config/dpconfig/zero2_offload.json — without the CPU offload: 288 GB of HBM hold it).
+    max_grad_norm: global-norm gradient clipping with torch.nn.utils.clip_grad_norm_ arithmetic (HF Trainer's
+    max_grad_norm = 1.0 reaches DeepSpeed through `"gradient_clipping": "auto"`); norm and coefficient stay on the device."""
+
+    def __init__(self, gb: GradBuffer, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, dp=None, max_grad_norm=None):
+        self.gb, self.dp = gb, dp
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
         dev = gb.flat.device
-        self.master = torch.empty(gb.numel, device=dev, dtype=torch.float32)
-        self.m = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
-        self.v = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
+        self.items = []                         # (kind, obj, lo, hi, state offset, counted in global reductions)
+        soff = 0
+        for (kind, obj, n), off in zip(gb.spans, gb.offsets):
+            lo, hi, counted = (dp.owned(obj, kind) if dp is not None and dp.gb is gb else (off, off + n, True))
+            self.items.append((kind, obj, lo, hi, soff, counted, off))
+            soff += hi - lo
+        self.n_state = soff
+        self.master = torch.empty(soff, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(soff, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(soff, device=dev, dtype=torch.float32)
         self.step_count = 0
         self._scratch = {}
         self._stream = None
-        for (kind, obj, n), off in zip(gb.spans, gb.offsets):
-            src = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
-            self.master[off:off + n].copy_(src.reshape(-1).float())
+        self._ss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._coef = torch.ones(1, device=dev, dtype=torch.float32)
+        self._part = torch.empty(1024, device=dev, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)      # norm of the MEAN gradient at the last step
+        self.resync_master()
 
-    def _update(self, kind, obj, off, n, lr, grad_scale, zero_grad):
-        tgt = obj.w if kind == "w" else obj.b if kind == "b" else obj.data
+    @staticmethod
+    def _target(kind, obj):
+        return obj.w if kind == "w" else obj.b if kind == "b" else obj.data
+
+    def resync_master(self):
+        """fp32 masters <- current weights (construction; after a checkpoint was loaded into the model)."""
+        for kind, obj, lo, hi, soff, _, off in self.items:
+            src = self._target(kind, obj).reshape(-1)[lo - off:hi - off]
+            self.master[soff:soff + hi - lo].copy_(src.float())
+
+    def _update(self, kind, obj, lo, hi, soff, off, lr, grad_scale, zero_grad, dev_scale):
+        tgt = self._target(kind, obj)
+        n = hi - lo
+        if n == 0:
+            return
         if tgt.dtype == BF16:
-            pb = tgt
+            pb = tgt.reshape(-1)[lo - off:hi - off]
         else:                                   # fp32 parameter (router wg): bf16 copy goes to scratch
             pb = self._scratch.setdefault(n, torch.empty(n, device=tgt.device, dtype=BF16))
-        K.adamw_step(self.master[off:off + n], pb, self.gb.flat[off:off + n], self.m[off:off + n],
-                     self.v[off:off + n], lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                     grad_scale, zero_grad=zero_grad)
+        K.adamw_step(self.master[soff:soff + n], pb, self.gb.flat[lo:hi], self.m[soff:soff + n], self.v[soff:soff + n],
+                     lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
+                     zero_grad=zero_grad, dev_scale=dev_scale)
         if tgt.dtype != BF16:
-            tgt.reshape(-1).copy_(self.master[off:off + n])
+            tgt.reshape(-1)[lo - off:hi - off].copy_(self.master[soff:soff + n])
         if kind == "w":
             obj._wt_version = None      # the kernel wrote behind torch's back: invalidate the cached W^T
 
+    def _clip_coef(self, grad_scale):
+        """Device-side clipping coefficient for the gradient SUM in gb.flat scaled by grad_scale (= the mean gradient)."""
+        first = True
+        for kind, obj, lo, hi, soff, counted, off in self.items:
+            if counted and hi > lo:
+                K.sumsq(self.gb.flat[lo:hi], self._ss, self._part, accumulate=not first)
+                first = False
+        if first:
+            self._ss.zero_()
+        if self.dp is not None and self.dp.enabled:
+            dist.all_reduce(self._ss, op=dist.ReduceOp.SUM)
+        K.clip_coef(self._ss, grad_scale, self.max_grad_norm, self._coef, self.grad_norm)
+        return self._coef
+
     def step(self, grad_scale=1.0, lr=None, overlap=False, clear_grads=False):
-        """One AdamW update of every span.  overlap=True is the just-in-time form: the fused weights (99.9 % of the
-        bytes) are updated on the optimizer's own stream in the order the next forward will touch them, each one
-        publishing an event that `FusedWeight.ensure()` waits on, so this HBM-bound pass runs under the next step's
-        forward GEMMs instead of in front of them; every span also clears its gradient in the same pass (GradBuffer.zero()
-        then skips the memset).  Arithmetic and results are identical to the serial form.  Call `sync()` before reading
-        weights outside a forward."""
+        """One AdamW update of every span this rank owns.  overlap=True (unsharded only) is the just-in-time form: the fused
+        weights (99.9 % of the bytes) are updated on the optimizer's own stream in the order the next forward will touch
+        them, each one publishing an event that `FusedWeight.ensure()` waits on; every span also clears its gradient in the
+        same pass (GradBuffer.zero() then skips the memset).  Arithmetic and results are identical to the serial form.
+        Call `sync()` before reading weights outside a forward."""
         self.step_count += 1
         lr = self.lr if lr is None else lr
-        spans = list(zip(self.gb.spans, self.gb.offsets))
-        if not overlap:
+        zero2 = self.dp is not None and self.dp.zero2
+        dev_scale = self._clip_coef(grad_scale) if self.max_grad_norm else None
+        if zero2 or not overlap:
             # clear_grads: every span zeroes its gradient in the same pass, so the next GradBuffer.zero() skips its
             # 8 GB memset (optimizer.zero_grad() folded into the update)
-            for (kind, obj, n), off in spans:
-                self._update(kind, obj, off, n, lr, grad_scale, clear_grads)
+            for kind, obj, lo, hi, soff, _, off in self.items:
+                self._update(kind, obj, lo, hi, soff, off, lr, grad_scale, clear_grads and not zero2, dev_scale)
+            if zero2:
+                self._gather_params()
+                if clear_grads:               # chunks of other ranks hold un-reduced partial sums: one memset of the buffer
+                    self.gb.flat.zero_()
             if clear_grads:
                 self.gb.clean = True
             return
         deferred, inline = {}, []
-        for (kind, obj, n), off in spans:
+        for kind, obj, lo, hi, soff, _, off in self.items:
             if kind in ("w", "b") and obj._use_seq is not None:
-                deferred.setdefault(id(obj), (obj, []))[1].append((kind, off, n))
+                deferred.setdefault(id(obj), (obj, []))[1].append((kind, lo, hi, soff, off))
             else:
-                inline.append((kind, obj, off, n))
-        for kind, obj, off, n in inline:                     # small / not-yet-ordered spans: in line
-            self._update(kind, obj, off, n, lr, grad_scale, True)
+                inline.append((kind, obj, lo, hi, soff, off))
+        for kind, obj, lo, hi, soff, off in inline:          # small / not-yet-ordered spans: in line
+            self._update(kind, obj, lo, hi, soff, off, lr, grad_scale, True, dev_scale)
         cur = torch.cuda.current_stream()
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=self.gb.flat.device, priority=cur.priority)
-        self._stream.wait_stream(cur)                        # gradients (and their all-reduce) are final on `cur`
+        self._stream.wait_stream(cur)                        # gradients (and their exchange) are final on `cur`
         with torch.cuda.stream(self._stream):
             for obj, parts in sorted(deferred.values(), key=lambda t: t[0]._use_seq):
-                for kind, off, n in parts:
-                    self._update(kind, obj, off, n, lr, grad_scale, True)
+                for kind, lo, hi, soff, off in parts:
+                    self._update(kind, obj, lo, hi, soff, off, lr, grad_scale, True, dev_scale)
                 ev = torch.cuda.Event()
                 ev.record(self._stream)
                 obj._ready = ev
         self.gb.clean = True
+
+    def _gather_params(self):
+        """ZeRO-2: every rank publishes its updated bf16 chunks; in-place all-gather into the flat parameter buffer."""
+        handles = []
+        for kind, obj, lo, hi, soff, _, off in self.items:
+            info = self.dp.plan[(id(obj), kind)]
+            if info["sharded"]:
+                full = self.gb.pflat[off:off + info["n"]]
+                handles.append(dist.all_gather_into_tensor(full, self.gb.pflat[lo:hi], group=info["group"], async_op=True))
+        for h in handles:
+            h.wait()
 
     def sync(self):
         """Make the current stream wait for an overlapped step (before reading weights outside a forward)."""

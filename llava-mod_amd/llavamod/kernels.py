@@ -221,9 +221,29 @@ def vit_embed(patch_emb, cls, pos, B, n_patches):
     return out
 
 
-def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, zero_grad=False):
+def adamw_step(master, param, grad, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, zero_grad=False,
+               dev_scale=None):
     call("lmod_adamw_step", ptr(master), ptr(param), ptr(grad), ptr(m), ptr(v), master.numel(), float(lr),
-         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), int(zero_grad))
+         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), int(zero_grad), ptr(dev_scale))
+
+
+def sumsq(x, out, partials, accumulate=False):
+    """out[0] (+)= sum(x^2) for a contiguous fp32 tensor (deterministic)."""
+    call("lmod_sumsq_f32", ptr(x), x.numel(), ptr(partials), ptr(out), int(accumulate))
+    return out
+
+
+def clip_coef(sumsq_t, norm_scale, max_norm, coef, norm_out=None):
+    call("lmod_clip_coef", ptr(sumsq_t), float(norm_scale), float(max_norm), ptr(coef), ptr(norm_out))
+    return coef
+
+
+def cast_f32_bf16(src, dst):
+    """Elementwise fp32 -> bf16 or bf16 -> fp32 between two contiguous tensors of equal numel."""
+    to_bf16 = src.dtype == torch.float32
+    assert dst.dtype == (BF16 if to_bf16 else torch.float32) and src.numel() == dst.numel()
+    call("lmod_cast_f32_bf16", ptr(src), ptr(dst), src.numel(), int(to_bf16))
+    return dst
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -58,7 +58,8 @@ def build_loss_plan(labels_np, lens_np, kd_rows=True, ce_rows=True, distill_all_
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return SimpleNamespace(R=len(rows), row_idx=t(rows), inv_row_idx=t(inv), kd_w=t(kd[bi, ti].astype(np.float32)),
                            ce_w=t(ce[bi, ti].astype(np.float32)), ce_label=t(ce_label[bi, ti]),
-                           seg_off=t(seg_off), seg_id=t(bi.astype(np.int32)), align_vocab=align_vocab,
+                           seg_off=t(seg_off), seg_id=t(bi.astype(np.int32)), align_vocab=align_vocab, shape=(B, S),
+                           labels_np=labels_np,
                            n_kd=int(kd.sum()), n_ce=int(ce.sum()))
 
 

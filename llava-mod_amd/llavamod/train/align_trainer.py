@@ -60,6 +60,9 @@ class AlignTrainer:
         """Student and teacher normally load the SAME frozen CLIP checkpoint (`--image_tower` is one flag in the
         reference's shells); when their towers are frozen and bit-identical the features are computed once per batch
         and shared (the reference runs the tower twice).  Checked once, on the actual weights."""
+        epoch = (getattr(self.model, "_weights_epoch", 0), getattr(self.ref_model, "_weights_epoch", 0))
+        if getattr(self, "_tower_epoch", None) != epoch:         # a checkpoint was loaded since the last check
+            self._tower_shared, self._tower_epoch = None, epoch
         if getattr(self, "_tower_shared", None) is None:
             ok = False
             ts, tt = self.model.get_image_tower(), self.ref_model.get_image_tower()
@@ -102,8 +105,17 @@ class AlignTrainer:
         teacher_plan, t_logits = teacher.plan, teacher.logits
         if teacher.tower_feats is not None:
             model._shared_tower_feats = teacher.tower_feats          # consumed by the student's encode_images below
-        # same inputs => same spliced labels => same loss rows: the student's last (dense) layer is trimmed the same way
-        s_hidden, moe_list, s_info = model.forward_hidden(**batch, plan_fn=lambda info: copy.copy(teacher_plan))
+        # same inputs => same spliced labels => same loss rows: the student's last (dense) layer is trimmed the same way.
+        # The teacher's plan is only reused if the student's splice really produced the same layout: a different patch
+        # count or tokenizer_model_max_length would silently index the wrong rows (the reference raises on the logits'
+        # shape mismatch at this point, align_trainer.py:470-471).
+        def student_plan(info):
+            tp = teacher_plan
+            if tp.shape != (info.B, info.S) or not (tp.labels_np == info.labels_np).all():
+                raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape: the student's and "
+                                 f"the teacher's spliced sequences differ ({(info.B, info.S)} vs {tp.shape})")
+            return copy.copy(tp)
+        s_hidden, moe_list, s_info = model.forward_hidden(**batch, plan_fn=student_plan)
         plan = s_info.plan
         kd_sum, kd_cnt, ce_sum, ce_cnt = ops.DistillHead.apply(s_hidden, model.head(), plan, t_logits,
                                                                *model._head_trainable())
@@ -114,9 +126,12 @@ class AlignTrainer:
             policy_sft_loss = policy_sft_loss + moe_all                        # outputs.loss already carries it
         policy_moe_loss = moe_all if (getattr(self.args, "moe_enable", True) and self.moe_loss_enable) else None
         losses = align_loss if self.loss_type == "only_kd" else align_loss + policy_sft_loss   # :570-573
-        if policy_moe_loss is not None and bool(policy_moe_loss):              # `if policy_moe_loss:` (:575)
-            moe_loss = policy_moe_loss
-            losses = losses + moe_loss
+        if policy_moe_loss is not None:
+            # `if policy_moe_loss:` (:575) is tensor truthiness: a balance loss of exactly 0 is logged as -1 and not added.
+            # Adding 0 changes nothing, so only the LOGGED value needs the test — on the device, without a host sync
+            # (a bool() here stalled the teacher-prefetch pipeline every step).
+            losses = losses + policy_moe_loss
+            moe_loss = torch.where(policy_moe_loss.detach() != 0, policy_moe_loss.detach(), torch.full_like(align_loss, -1.0))
         else:
             moe_loss = torch.full_like(align_loss, -1.0)
         outputs = {"loss": losses.mean(), "loss/align": align_loss.mean(), "loss/moe_balance": moe_loss.mean(),

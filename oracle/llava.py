@@ -48,6 +48,27 @@ class LlavaOracle(nn.Module):
             m.noise = n
 
 
+def hip_to_oracle_key(k):
+    """State-dict key of the product models (= the reference's layout) -> key of `LlavaOracle` (inverse of the mapping the
+    parity tests use to load oracle weights into the product models)."""
+    if k.startswith("model.image_tower.image_tower."):
+        return "image_tower." + k[len("model.image_tower.image_tower."):]
+    if k.startswith("model.mm_projector."):
+        return k[len("model."):]
+    return "lm." + k
+
+
+def load_from_product_state(oracle_model: "LlavaOracle", state):
+    """Copy a product model's state dict (bf16 device tensors) into the fp32 oracle, key by key, strictly."""
+    own = oracle_model.state_dict()
+    mapped = {hip_to_oracle_key(k): v for k, v in state.items()}
+    assert set(mapped) == set(own), sorted(set(mapped) ^ set(own))[:8]
+    with torch.no_grad():
+        for k, t in own.items():
+            t.copy_(mapped[k].detach().to(device="cpu", dtype=t.dtype))
+    return oracle_model
+
+
 def freeze_like_d2s(student: LlavaOracle):
     """Trainable set of the dense-to-sparse stage: FFNs (dense + experts) + routers `wg`
     + mm_projector; everything else frozen (llava_qwen2_moe.py:501-506, llava_arch.py:115-120)."""

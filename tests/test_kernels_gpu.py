@@ -664,3 +664,47 @@ def test_abi_error_codes_and_empty_inputs():
         K.gemm_nt(rnd(8, 12, seed=83), rnd(8, 12, seed=84))             # K = 12 through the binding
     assert K.gemm_nt(a[:0], b).shape == (0, 64)                         # zero rows: allocates, launches nothing
     torch.cuda.synchronize()
+
+
+def test_sumsq_clip_cast_and_adamw_device_scale():
+    """Gradient-clipping pieces: deterministic sum of squares (accumulating over spans), clip coefficient with
+    torch.nn.utils.clip_grad_norm_ arithmetic, AdamW reading that coefficient from the device; fp32 <-> bf16 casts."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1_000_003, generator=g).to(DEV)
+    y = torch.randn(4099, generator=g).to(DEV)
+    part = torch.empty(1024, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    K.sumsq(x, out, part)
+    K.sumsq(y[3:4099 - 0].contiguous(), out, part, accumulate=True)
+    ref = (x.double() ** 2).sum() + (y[3:].double() ** 2).sum()
+    assert abs(out.item() - ref.item()) <= 1e-5 * ref.item()
+    out2 = torch.zeros(1, device=DEV)
+    K.sumsq(x, out2, part)
+    K.sumsq(y[3:].contiguous(), out2, part, accumulate=True)
+    assert torch.equal(out, out2)                               # fixed reduction order: bit-identical run to run
+    coef, nrm = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    K.clip_coef(out, 0.5, 1.0, coef, nrm)
+    n_ref = math.sqrt(ref.item()) * 0.5
+    assert abs(nrm.item() - n_ref) <= 1e-5 * n_ref and abs(coef.item() - min(1.0, 1.0 / (n_ref + 1e-6))) <= 1e-6
+    K.clip_coef(out, 1e-6, 1.0, coef)
+    assert coef.item() == 1.0                                   # small norm: no clipping
+    # AdamW with the coefficient read on the device == AdamW with the product folded into grad_scale on the host
+    n = 10007
+    master = torch.randn(n, generator=g).to(DEV)
+    grad = torch.randn(n, generator=g).to(DEV)
+    K.clip_coef(out, 0.5, 1.0, coef)
+    runs = []
+    for dev_scale, gs in ((coef, 0.5), (None, 0.5 * coef.item())):
+        ms, gr = master.clone(), grad.clone()
+        m, v, pb = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.empty(n, device=DEV, dtype=BF)
+        K.adamw_step(ms, pb, gr, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.1, 1, gs, dev_scale=dev_scale)
+        runs.append((ms, m, v))
+    for a, b in zip(*runs):
+        close(a, b, "adamw dev scale", rtol=1e-5, afrac=1e-7)
+    # casts
+    xb = torch.empty(x.numel(), device=DEV, dtype=BF)
+    K.cast_f32_bf16(x, xb)
+    assert torch.equal(xb, x.to(BF))
+    xf = torch.empty_like(x)
+    K.cast_f32_bf16(xb, xf)
+    assert torch.equal(xf, xb.float())

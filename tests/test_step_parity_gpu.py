@@ -439,3 +439,103 @@ def test_overlapped_optimizer_is_exact_over_steps():
         for a, b in zip(runs[0][1:4], other[1:4]):
             assert torch.equal(a, b)
         assert all(torch.equal(runs[0][4][k], other[4][k]) for k in runs[0][4])
+
+
+def test_clipped_accumulated_step_matches_torch_reference():
+    """One optimizer step over a 2-micro-batch accumulation window with global-norm clipping: the gradient buffer holds
+    the SUM of the micro-batch gradients, the norm/coefficient are those of torch.nn.utils.clip_grad_norm_ on the mean
+    gradient, and the update equals torch.optim.AdamW on the clipped mean gradient."""
+    from llavamod.engine import GradBuffer, HipAdamW
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    batches = [_batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")]
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=512)
+    gb = GradBuffer(student)
+    singles = []
+    for b in batches:
+        gb.zero()
+        tr.training_step(student, b)
+        singles.append(gb.flat.clone())
+    gb.zero()
+    for b in batches:                                             # accumulation window: no zero in between
+        tr.training_step(student, b)
+    total = singles[0] + singles[1]
+    assert (gb.flat - total).abs().max().item() <= 1e-5 * total.abs().max().item()
+    max_norm = 0.25 * float((gb.flat * 0.5).norm())               # force clipping
+    opt = HipAdamW(gb, lr=1e-3, weight_decay=0.01, max_grad_norm=max_norm)
+    p0 = opt.master.clone()
+    mean_grad = gb.flat.clone() * 0.5
+    opt.step(grad_scale=0.5, clear_grads=True)
+    torch.cuda.synchronize()
+    assert abs(float(opt.grad_norm) - float(mean_grad.norm())) <= 1e-4 * float(mean_grad.norm())
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref_p.grad = mean_grad.clone()
+    torch.nn.utils.clip_grad_norm_([ref_p], max_norm)
+    ropt = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    ropt.step()
+    err = (opt.master - ref_p.data).abs().max().item()
+    assert err <= 2e-6, err
+    assert gb.flat.abs().max().item() == 0
+
+
+def _nccl_zero2_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
+    from llavamod.train.align_trainer import AlignTrainer
+    init_distributed()
+    dev = f"cuda:{rank}"
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    batches = [_batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")]
+    res = {}
+    for mode in ("allreduce", "zero2"):
+        student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, dev)
+        for m in student.moe_layers():
+            m.deterministic = True
+        tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                                   loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=512)
+        gb = GradBuffer(student)
+        dp = DataParallel(zero2=(mode == "zero2"), min_shard_numel=1).attach(gb)
+        opt = HipAdamW(gb, lr=1e-3, weight_decay=0.01, dp=dp, max_grad_norm=1.0)
+        for i in range(3):
+            gb.zero()
+            tr.training_step(student, batches[(i + rank) % 2])   # the two ranks see different data
+            dp.finish()
+            opt.step(grad_scale=1.0 / world, clear_grads=True)
+        torch.cuda.synchronize()
+        res[mode] = {k: v.detach().float().cpu() for k, v in student.state_dict().items()}
+    bad = [k for k in res["allreduce"] if not torch.allclose(res["allreduce"][k], res["zero2"][k], rtol=0, atol=1e-6)]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bad))
+
+
+def test_two_gpu_zero2_equals_allreduce_over_rccl():
+    """N = 2 over RCCL on real devices: ZeRO-2 style sharded step == all-reduce step (self-skips on a 1-GPU box; the
+    CPU twin is tests/test_dp_gloo.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_zero2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for _ in range(2):
+        rank, bad = q.get(timeout=5)
+        assert not bad, (rank, bad[:5])
