@@ -121,9 +121,13 @@ class DPOTrainer:
         rc, rr = reference.chosen, reference.rejected
         reward_losses, chosen_rewards, rejected_rewards = self.dpo_loss(pc, pr, rc, rr)
         reward_mean = self._last_mean                           # differentiable mean of reward_losses
-        if pc_moe is not None and pr_moe is not None and bool(pc_moe) and bool(pr_moe):   # :614-616
-            moe_loss = pc_moe + pr_moe
-            total = reward_mean + moe_loss                      # (reward_losses + moe).mean()
+        if pc_moe is not None and pr_moe is not None:
+            # `if policy_chosen_moe_loss and policy_rejected_moe_loss:` (:614-616) is tensor truthiness; decided on the
+            # device (a bool() here is a host sync in the middle of the step): the sum is added only if BOTH are non-zero
+            both = (pc_moe.detach() != 0) & (pr_moe.detach() != 0)
+            added = torch.where(both, pc_moe + pr_moe, torch.zeros_like(reward_mean))
+            total = reward_mean + added                         # (reward_losses + moe).mean()
+            moe_loss = torch.where(both, added.detach(), torch.full_like(reward_mean, -1.0))
         else:
             moe_loss = torch.full_like(reward_mean, -1.0)
             total = reward_mean

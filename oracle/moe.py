@@ -125,7 +125,8 @@ class OracleMoE(nn.Module):
         logits = F.linear(x.float(), wg.weight.float())
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 2:
-            l_aux, combine, dispatch, exp_counts = top2gating(logits, cf, self.min_capacity, self.noise, self.forced)
+            forced = self.forced.pop(0) if isinstance(self.forced, list) else self.forced     # list: one entry per call
+            l_aux, combine, dispatch, exp_counts = top2gating(logits, cf, self.min_capacity, self.noise, forced)
             g = F.softmax(logits.detach(), dim=1)
             i1 = torch.argmax(g, dim=1)
             lw = logits.detach() if self.noise is None else logits.detach() + self.noise

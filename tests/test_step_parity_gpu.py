@@ -3,8 +3,11 @@ oracle run on the same seeded inputs, on a real MI355X, through the reference's 
 
 Tolerance (north_star: "within 1e-3 bf16 tolerance"): the GPU path keeps activations in bf16 exactly
 where the reference's bf16 run does, the oracle computes in fp32 on the same bf16-rounded weights, so
-the residual is bf16 activation rounding.  Losses must agree to 1e-3 relative; logits to 1e-3 of
-their scale + 2 bf16 ulp; gradients to 3e-2 of each tensor's max (bf16 backward, fp32 accumulation).
+the residual is bf16 activation rounding.  Loss scalars and sequence log-probabilities must agree to
+1e-3 relative.  Quantities whose natural scale is not their own magnitude — gradients, DPO loss /
+reward (differences of ~-150 sums), materialised log-probabilities — are held to 2x their measured
+bf16 NOISE FLOOR: the oracle's own bf16 twin (`_bf16_twin`) against the fp32 oracle, same inputs, same
+routing.  Golden small case: logits to 1e-3 of their scale + 2 bf16 ulp, gradients 3e-2 of the max.
 """
 import os
 import sys
@@ -118,6 +121,24 @@ def test_golden_small_mimic_step(tag):
     assert len(grads) > 10 and worst > 0
 
 
+def _bf16_twin(model):
+    """The same oracle module with bf16 weights and activations (router kept fp32, as DeepSpeed keeps it): what the
+    reference's own bf16 training run computes.  |twin - fp32 oracle| is the bf16 NOISE FLOOR of a quantity; the GPU path,
+    which keeps bf16 exactly where the reference does, is held to 2x that floor wherever north_star's flat 1e-3 is not the
+    natural scale of the quantity (differences of large numbers, gradients of discontinuously routed experts)."""
+    import copy
+    m = copy.deepcopy(model)
+    for n, p in m.named_parameters():
+        if "gate.wg" not in n:
+            p.data = p.data.to(torch.bfloat16)
+        p.grad = None
+    return m
+
+
+def _bf16_batch(batch):
+    return {k: (v.to(torch.bfloat16) if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+
+
 def _seeded_pair(seed, sc, tc, vc):
     teacher = init_weights(LlavaOracle(tc, vc, moe=False), seed=seed + 100)
     student = sync_experts_from_dense(init_weights(LlavaOracle(sc, vc, moe=True), seed=seed))
@@ -223,9 +244,125 @@ def test_seeded_mid_mimic_step_vs_oracle(ragged, noise):
     ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
     hgrads = _grads_of(student)
     assert set(ograds) == set(hgrads), sorted(set(ograds) ^ set(hgrads))[:8]
+    # bf16 noise floor of every gradient: the oracle's bf16 twin with the same forced picks
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(noises)
+    for hm, om in zip(student.moe_layers(), _oracle_moes(tw_s)):
+        om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
+    _, logs_f, _, _ = mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=sc.vocab_size)
+    fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
+    worst = (0.0, None, 0.0)
     for n, ref in ograds.items():
-        e = U.relerr(hgrads[n], ref)
-        assert e <= 4e-2, (n, e)
+        e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
+        assert e <= max(2.0 * floor, 5e-3), (n, e, floor)
+        worst = max(worst, (e, n, floor))
+    print(f"mid mimic (ragged={ragged}, noise={noise}): worst gradient error {worst[0]:.4f} ({worst[1]}), its bf16 floor "
+          f"{worst[2]:.4f}; loss floor {abs(float(logs_f['loss']) - float(logs_o['loss'])) / abs(float(logs_o['loss'])):.2e}")
+
+
+def test_mid_mimic_step_free_running_routing():
+    """No routing hook at all: a seed (found offline with the CPU oracle, 600 candidates) for which EVERY routing decision of
+    both MoE layers — first and second pick — has a margin > 4e-2 of the token's largest |router logit| in the oracle.  bf16
+    hidden states carry ~1 % relative noise after a few layers (tests/test_full_width_gpu.py measures it), so the GPU path
+    must then make exactly the same picks on its own, and losses / gradients must agree without forcing anything."""
+    from llavamod.engine import GradBuffer
+    from llavamod.train.align_trainer import AlignTrainer
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    vc, sc, tc = _mid_cfgs()
+    o_student, o_teacher = _seeded_pair(613, sc, tc, vc)
+    with torch.no_grad():
+        for m in _oracle_moes(o_student):
+            m.deepspeed_moe.gate.wg.weight.mul_(32.0)
+    batch = _mid_batch(620, 1, 12, sc.vocab_size, vc.image_size, False)
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    for m in _oracle_moes(o_student):                          # the premise: no near-tie anywhere
+        i1, i2, g, lw = m.last_picks
+        ls = lw.sort(dim=1, descending=True).values
+        scale = lw.abs().max(dim=1).values.clamp_min(1.0)
+        assert ((ls[:, 0] - ls[:, 1]) / scale).min().item() > 4e-2 and ((ls[:, 1] - ls[:, 2]) / scale).min().item() > 4e-2
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    GradBuffer(student)
+    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))(),
+                      align_vocab=sc.vocab_size)
+    student.train()
+    loss, outs = tr.compute_loss(student, hb, return_outputs=True)
+    loss.backward()
+    for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
+        i1, i2, _, _ = om.last_picks
+        assert torch.equal(hm.last_state.idx1.cpu().long(), i1) and torch.equal(hm.last_state.idx2.cpu().long(), i2)
+    for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
+        got, exp = float(outs[k].detach()), float(logs_o[k].detach())
+        assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise([None, None])
+    mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=sc.vocab_size)
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
+    hgrads = _grads_of(student)
+    assert set(ograds) == set(hgrads)
+    for n, ref in ograds.items():
+        e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
+        assert e <= max(2.0 * floor, 5e-3), (n, e, floor)
+
+
+def test_finetune_student_and_top1_step():
+    """`LLaVAMoDQwen2ForCausalLMFineTune` (the class the preference stage constructs, llava_qwen2_moe.py:564-626): built
+    from a saved config.moe it has the up-cycled student's exact state-dict layout, loads its weights, reproduces its
+    outputs bit for bit and sets trainability by substring.  Then a top-1 student (k = 1, token-order selection) steps
+    against the oracle's top1gating."""
+    import copy
+    from llavamod.engine import GradBuffer
+    from llavamod.model.language_model.llava_qwen2_moe import LLaVAMoDQwen2ForCausalLMFineTune
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    cfg = copy.deepcopy(student.config)
+    ft = LLaVAMoDQwen2ForCausalLMFineTune(cfg, device=DEV)
+    assert list(ft.state_dict().keys()) == list(student.state_dict().keys())
+    ft.load_state_dict(student.state_dict())
+    ft.initialize_moe_modules(type("A", (), dict(train_modules=["mlp.gate_proj", "mlp.up_proj", "mlp.down_proj", "wg"]))())
+    names = {n for n, p in ft.named_parameters() if p.requires_grad}
+    assert names and all(any(t in n for t in ("mlp.gate_proj", "mlp.up_proj", "mlp.down_proj", "wg")) for n in names)
+    batch = _batch_from(g, "plain")
+    for m in list(student.moe_layers()) + list(ft.moe_layers()):
+        m.deterministic = True
+    student.train(); ft.train()
+    with torch.no_grad():
+        a, b = student(**batch), ft(**batch)
+    assert torch.equal(a.logits, b.logits) and float(a.loss) == float(b.loss) and float(a.moe_loss) == float(b.moe_loss)
+    # top-1 gating, k = 1 (token-order capacity selection; DeepSpeed's random token selection needs explicit noise)
+    sc1 = copy.deepcopy(sc)
+    sc1.top_k_experts = 1
+    o_student = LlavaOracle(sc1, vc, moe=True)
+    o_student.load_state_dict(ssd)
+    o_teacher = LlavaOracle(tc, vc, moe=False)
+    o_teacher.load_state_dict(tsd)
+    freeze_like_d2s(o_student)
+    ob = {k: g["plain.batch." + k] for k in ("input_ids", "attention_mask", "labels", "images")}
+    ob["attention_mask"] = ob["attention_mask"].bool()
+    o_student.train(); o_teacher.eval()
+    for m in _oracle_moes(o_student):
+        m.rts_noise = None                                      # token order
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, ob, loss_type="kd_lm", align_vocab=512)
+    s1, t1 = U.build_hip_pair(ssd, tsd, sc1, tc, vc, DEV)
+    GradBuffer(s1)
+    tr = AlignTrainer(s1, t1, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False, loss_type="kd_lm",
+                                                      moe_loss_enable=True))(), align_vocab=512)
+    s1.train()
+    loss, outs = tr.compute_loss(s1, batch, return_outputs=True)
+    loss.backward()
+    for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
+        got, exp = float(outs[k].detach()), float(logs_o[k].detach())
+        assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    _check_grads(_grads_of(s1), ograds, 3e-2, 5e-2)
 
 
 @pytest.mark.parametrize("loss_type", ["sigmoid", "kto_pair"])
@@ -239,25 +376,46 @@ def test_seeded_mid_dpo_step_vs_oracle(loss_type):
     batch = dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"], chosen_attention_mask=ch["attention_mask"],
                  rejected_input_ids=rj["input_ids"], rejected_labels=rj["labels"],
                  rejected_attention_mask=rj["attention_mask"], images=ch["images"])
-    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
-    loss_o, logs_o = dpo_step(o_student, o_teacher, batch, beta=0.1, loss_type=loss_type)
     student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
-    for m in student.moe_layers():
+    picks = {}
+    for li, m in enumerate(student.moe_layers()):            # record the routing picks of every call (chosen, rejected)
         m.deterministic = True
+        picks[li] = []
+        m.register_forward_hook(lambda mod, a, o, li=li: picks[li].append((mod.last_state.idx1.cpu(), mod.last_state.idx2.cpu())))
     GradBuffer(student)
     hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
     tr = DPOTrainer(student, teacher, beta=0.1, loss_type=loss_type)
     student.train()
     loss, outs = tr.compute_loss(student, hb, return_outputs=True)
     loss.backward()
-    # sequence log-probs are sums of ~20 token logps (~ -150): 1e-3 relative; the reward terms are differences
+    # oracle with the GPU path's picks forced, call by call (a discontinuous argmax is not a rounding question; the mimic
+    # tests gate the agreement rate, this one checks the arithmetic around it)
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
+    for li, om in enumerate(_oracle_moes(o_student)):
+        om.forced = list(picks[li])
+    loss_o, logs_o = dpo_step(o_student, o_teacher, batch, beta=0.1, loss_type=loss_type)
+    # bf16 noise floor: the oracle's bf16 twin on the same batch with the same picks
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise([None, None])
+    for li, om in enumerate(_oracle_moes(tw_s)):
+        om.forced = list(picks[li])
+    bb = {k: (v.to(torch.bfloat16) if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+    _, logs_f = dpo_step(tw_s, tw_t, bb, beta=0.1, loss_type=loss_type)
+    # sequence log-probs are sums of ~20 token logps (~ -150): 1e-3 relative; loss / reward are differences of those sums:
+    # their natural scale is the noise floor of the difference
     for k in ("logps/chosen", "logps/rejected"):
         assert abs(float(outs[k]) - float(logs_o[k])) <= 1e-3 * abs(float(logs_o[k])), (k, float(outs[k]), float(logs_o[k]))
     for k in ("loss", "loss/reward", "loss/moe_balance"):
-        assert abs(float(outs[k]) - float(logs_o[k])) <= 5e-3 * max(1.0, abs(float(logs_o[k]))), (k, float(outs[k]), float(logs_o[k]))
+        floor = abs(float(logs_f[k]) - float(logs_o[k]))
+        assert abs(float(outs[k]) - float(logs_o[k])) <= max(2.0 * floor, 1e-3 * abs(float(logs_o[k]))), \
+            (k, float(outs[k]), float(logs_o[k]), floor)
     ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
     hgrads = _grads_of(student)
-    _check_grads(hgrads, ograds, 6e-2, 0.3)
+    assert set(ograds) == set(hgrads)
+    for n, ref in ograds.items():
+        e, floor = _froerr(hgrads[n], ref), _froerr(fgrads[n].float(), ref)
+        assert e <= max(2.0 * floor, 1e-2), (n, e, floor)
 
 
 def test_materialising_api_matches_oracle():
@@ -278,7 +436,16 @@ def test_materialising_api_matches_oracle():
     ref_p = olosses.get_p(g["plain.teacher_logits"], 512)
     ref_lp = olosses.get_logp(g["plain.student_logits"], 512)
     assert (p.cpu() - ref_p).abs().max() < 1e-4
-    assert (lp.cpu() - ref_lp).abs().max() < 2e-2
+    # log-probabilities ~ -6: the student's bf16 noise floor is measured on the oracle's bf16 twin of the same model
+    o_student = LlavaOracle(sc, vc, moe=True)
+    o_student.load_state_dict(ssd)
+    tw = _bf16_twin(o_student)
+    tw.train(); tw.set_gate_noise([None])
+    ob = {k: g["plain.batch." + k] for k in ("input_ids", "attention_mask", "labels", "images")}
+    ob["attention_mask"] = ob["attention_mask"].bool()
+    with torch.no_grad():
+        floor = (olosses.get_logp(tw(**_bf16_batch(ob)).logits.float(), 512) - ref_lp).abs().max().item()
+    assert (lp.cpu() - ref_lp).abs().max().item() <= max(2.0 * floor, 1e-3), ((lp.cpu() - ref_lp).abs().max().item(), floor)
     ref_al = olosses.compute_align_loss(ref_lp, ref_p, g["plain.labels"])
     assert abs(float(al) - float(ref_al)) <= 1e-3 * abs(float(ref_al))
 
