@@ -150,11 +150,17 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
  * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32). */
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);
 /* top-k (k in {1,2}) gating with capacity C: token-order slot assignment, drops, renormalised
- * combine weights, l_aux, exp_counts, slots_used[E] (live rows per capacity slab).  noise: additive [T,E]
- * noise for the 2nd choice or NULL.  scratch: 2*T + 24*ceil(T/512) int32. */
+ * combine weights, l_aux, exp_counts, slots_used[E] (live rows per capacity slab).
+ * k = 2 (top2gating): `noise` [T,E] is added to the logits for the 2nd choice (NULL: none); noise_mode 1 draws
+ *   Gumbel(0,1) noise in the kernel (Philox4x32-10 keyed by seed, counter = offset + token) — gumbel_rsample.
+ * k = 1 (top1gating): `noise` [T,E] holds the random-token-selection priorities (use_rts=True: per expert the C tokens
+ *   with the largest priority keep their slot, survivors numbered in token order; NULL: token order, use_rts=False);
+ *   noise_mode 2 draws U(0,1) priorities in the kernel.
+ * noise_out (nullable, [T,E]) receives the drawn noise.  scratch: 4*T + 24*ceil(T/512) int32. */
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
-                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream);
+                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, int noise_mode,
+                  unsigned long long seed, unsigned long long offset, float* noise_out, hipStream_t stream);
 /* out[t] = bf16(w1)*y[slot1[t]] + bf16(w2)*y[slot2[t]]   (einsum 'sec,ecm->sm'). */
 int lmod_moe_combine_fwd(const void* y, const int* slot1, const int* slot2, const float* w1, const float* w2,
                          void* out, int T, int H, hipStream_t stream);
@@ -169,6 +175,18 @@ int lmod_moe_dispatch_bwd(const void* d_in, const int* slot1, const int* slot2, 
 /* dwg[E,H] (+)= dlogits^T x (fp32 router weight gradient).  workspace: ceil(T/64) * E * H floats.  H % 8 == 0. */
 int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float* workspace, int T, int H, int E,
                           int accumulate, hipStream_t stream);
+
+/* Residual-MoE (deepspeed.moe.layer.MoE(use_residual=True); flag at config/args.py:54-56, passed through at
+ * llava_qwen2_moe.py:536-546): out = moe_out * c0 + mlp_out * c1 with (c0, c1) = softmax(coef_logits + coef_bias), the
+ * 2-way `coefficient` Linear(hidden, 2); roundings follow the bf16 module.  p[T,2] (fp32) is saved for the backward,
+ * which returns d_moe, d_mlp (bf16) and d_coef_logits[T,2] (fp32).  coef_logits come from lmod_moe_router_fwd (E = 2),
+ * the coefficient weight gradient from lmod_moe_router_wgrad, its input gradient from lmod_small_linear_dgrad:
+ * dx[T,H] (bf16) = dlogits[T,E] @ w[E,H] (fp32, E <= 8, H % 8 == 0). */
+int lmod_moe_residual_mix_fwd(const void* moe_out, const void* mlp_out, const float* coef_logits, const float* coef_bias,
+                              void* out, float* p, int T, int H, hipStream_t stream);
+int lmod_moe_residual_mix_bwd(const void* dout, const void* moe_out, const void* mlp_out, const float* p, void* d_moe,
+                              void* d_mlp, float* d_coef_logits, int T, int H, hipStream_t stream);
+int lmod_small_linear_dgrad(const float* dlogits, const float* w, void* dx, int T, int H, int E, hipStream_t stream);
 
 /* ---- distillation losses -----------------------------------------------------------------------
  * One pass per logits row.  stats[R][8] = {lse_s_full, lse_s_align, lse_t_align, x_kd, ce, s[label],

@@ -61,12 +61,61 @@ __global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restric
     }
 }
 
+// ---------------------------------------------------------------- counter-based random numbers (Philox4x32-10)
+// One call = 4 x 32 random bits for (key = seed, counter = (token + offset, stream)): no state, any token can be drawn by any
+// thread, reproducible from (seed, offset).  Replaces the torch.rand / log launches in front of every MoE layer
+// (sharded_moe.gumbel_rsample draws the top-2 noise; exp_selection_uniform_map the top-1 random-token-selection noise).
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// u in (0, 1): 24 random bits + half a step.  mode 1: Gumbel(0,1) = -log(-log(u)); mode 2: the uniform itself.
+__device__ __forceinline__ void draw_noise(float (&nz)[MAXE], long long t, int E, unsigned long long seed,
+                                           unsigned long long offset, int mode) {
+  const unsigned long long ctr = offset + (unsigned long long)t;
+#pragma unroll
+  for (int grp = 0; grp < MAXE / 4; ++grp) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)grp, 0u};
+    if (grp * 4 < E) philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = (float)(c[j] >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;
+      nz[grp * 4 + j] = (mode == 1) ? -logf(-logf(u)) : u;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- per-token softmax + top-2 picks
+// noise_mode 0: `noise` ([T,E], may be NULL) is what the caller supplies; 1 / 2: Gumbel / uniform noise is drawn here
+// (and written to noise_out if the caller wants to see it).  k == 2: the noise is added to the logits for the SECOND
+// pick (top2gating).  k == 1: the noise is the random-token-selection priority (top1gating, use_rts), consumed later.
 __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
                                                        float* __restrict__ gates, int* __restrict__ idx1,
-                                                       int* __restrict__ idx2, int T, int E, int k) {
+                                                       int* __restrict__ idx2, int T, int E, int k, int noise_mode,
+                                                       unsigned long long seed, unsigned long long offset,
+                                                       float* __restrict__ noise_out, float* __restrict__ prio) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
+  float nz[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) nz[e] = 0.f;
+  bool have_noise = (noise != nullptr);
+  if (noise_mode) {
+    draw_noise(nz, t, E, seed, offset, noise_mode);
+    have_noise = true;
+    if (noise_out) {
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) if (e < E) noise_out[(long long)t * E + e] = nz[e];
+    }
+  } else if (noise) {
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) if (e < E) nz[e] = noise[(long long)t * E + e];
+  }
   float l[MAXE], g[MAXE];
   float mx = -INFINITY;
 #pragma unroll
@@ -86,11 +135,68 @@ __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       if (e < E && e != i1) {
-        const float v = l[e] + (noise ? noise[(long long)t * E + e] : 0.f);
+        const float v = l[e] + nz[e];
         if (!any || v > b2) { b2 = v; i2 = e; any = true; }
       }
     }
     idx2[t] = i2;
+  } else if (prio && have_noise) {          // mask1 * uniform: the priority of this token inside its expert's queue
+    float pv = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) if (e == i1) pv = nz[e];
+    prio[t] = pv;
+  }
+}
+
+// ---------------------------------------------------------------- top-1 random token selection (use_rts)
+// top1gating keeps, per expert, the C tokens with the LARGEST priority (torch.topk over mask1 * uniform) and then numbers
+// the survivors in token order.  One block per expert: bisection on the float bit pattern (priorities are >= 0, so bit
+// order = value order) for the smallest threshold that keeps <= C tokens; ties at the boundary are filled in token order.
+// keep_idx[t] = idx1[t] if token t keeps its slot, -1 otherwise.
+__global__ __launch_bounds__(1024) void rts_select_kernel(const int* __restrict__ idx1, const float* __restrict__ prio,
+                                                         int* __restrict__ keep_idx, int T, int C) {
+  __shared__ int red[16];
+  __shared__ int bcast;
+  const int e = blockIdx.x, tid = threadIdx.x;
+  auto count_ge = [&](uint32_t thr) {
+    int c = 0;
+    for (int t = tid; t < T; t += 1024) c += (idx1[t] == e && __float_as_uint(prio[t]) >= thr) ? 1 : 0;
+    c = (int)wave_sum((float)c);             // counts <= 2^24: exact in fp32
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    return tot;
+  };
+  const int total = count_ge(0u);
+  uint32_t thr = 0u;
+  int kept = total;
+  if (total > C) {
+    uint32_t lo = 0u, hi = 0x7f800000u;      // f(lo) > C, f(hi) = 0 <= C ; find the smallest thr with f(thr) <= C
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (count_ge(mid) <= C) hi = mid; else lo = mid;
+    }
+    thr = hi;
+    kept = count_ge(thr);
+  }
+  int need = (total > C) ? C - kept : 0;     // > 0 only if several tokens tie just below the threshold
+  uint32_t tie = 0u;
+  if (need > 0) {                            // the tied value = thr - 1 (lo): bisection ended with f(lo) > C >= f(hi)
+    tie = thr - 1u;
+    if (tid == 0) bcast = 0;
+    __syncthreads();
+  }
+  for (int t = tid; t < T; t += 1024)
+    if (idx1[t] == e) keep_idx[t] = (__float_as_uint(prio[t]) >= thr) ? e : -1;     // each token has exactly one owner block
+  if (need > 0) {
+    __syncthreads();
+    if (tid == 0) {                          // rare: first `need` tied tokens in token order
+      for (int t = 0; t < T && need > 0; ++t)
+        if (idx1[t] == e && __float_as_uint(prio[t]) == tie) { keep_idx[t] = e; --need; }
+    }
   }
 }
 
@@ -152,7 +258,7 @@ __global__ __launch_bounds__(64) void moe_bases_kernel(int* __restrict__ part, c
     const int off = tot[tid - MAXE];
     for (int x = 0; x < nb; ++x) part[x * 2 * MAXE + tid] += off;
   }
-  if (tid == 0) {
+  if (tid == 0 && exp_counts) {
     float la = 0.f;
     for (int e = 0; e < E; ++e) {
       gate_sum[e] = gsum[e];
@@ -185,6 +291,7 @@ __global__ __launch_bounds__(SCAN_BLK) void moe_rank_kernel(const int* __restric
   __syncthreads();
   if (t >= T) return;
   const int* base = part + blockIdx.x * 2 * MAXE;
+  if (a < 0) { loc1[t] = 0x7fffffff; return; }      // top-1 random token selection dropped this token (k == 1 only)
   int p1 = base[a] + r1;
   for (int x = 0; x < w; ++x) p1 += wc[x][a];
   loc1[t] = p1;
@@ -446,6 +553,88 @@ static inline int grid_for(long long work, int cap = 256 * 16) {
   return (int)b;
 }
 
+// ---------------------------------------------------------------- Residual-MoE mix (deepspeed.moe.layer.MoE, use_residual)
+//   coef = softmax(Linear(hidden, 2)(x));  out = moe_out * coef[..., 0:1] + mlp(x) * coef[..., 1:]
+// One wave per token row.  Roundings follow the bf16 module: the 2 coefficient logits (fp32 dot + bias) are rounded to
+// bf16, so is the softmax output, each product and the sum.  p[T,2] (fp32, the bf16-rounded coefficients) is kept for backward.
+__global__ __launch_bounds__(256) void residual_mix_fwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                              const float* __restrict__ clog, const float* __restrict__ cbias,
+                                                              bf16_t* __restrict__ out, float* __restrict__ p, int T, int H) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float c0 = bfround(clog[t * 2] + cbias[0]), c1 = bfround(clog[t * 2 + 1] + cbias[1]);
+  const float m = fmaxf(c0, c1), e0 = expf(c0 - m), e1 = expf(c1 - m);
+  const float p0 = bfround(e0 / (e0 + e1)), p1 = bfround(e1 / (e0 + e1));
+  if (lane == 0) { p[t * 2] = p0; p[t * 2 + 1] = p1; }
+  for (int c = lane * 8; c < H; c += 512) {
+    const u32x4 av = *(const u32x4*)(a + t * H + c), bv = *(const u32x4*)(b + t * H + c);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = bfround(bflo(av[k]) * p0) + bfround(bflo(bv[k]) * p1);
+      const float hi = bfround(bfhi(av[k]) * p0) + bfround(bfhi(bv[k]) * p1);
+      o[k] = pack2bf(lo, hi);
+    }
+    *(u32x4*)(out + t * H + c) = o;
+  }
+}
+// d_a = dout * p0, d_b = dout * p1 (bf16); dc[t] = softmax backward of (dp0, dp1) = (sum_h dout*a, sum_h dout*b)
+__global__ __launch_bounds__(256) void residual_mix_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ a,
+                                                              const bf16_t* __restrict__ b, const float* __restrict__ p,
+                                                              bf16_t* __restrict__ da, bf16_t* __restrict__ db,
+                                                              float* __restrict__ dc, int T, int H) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float p0 = p[t * 2], p1 = p[t * 2 + 1];
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
+    const u32x4 dv = *(const u32x4*)(dout + t * H + c), av = *(const u32x4*)(a + t * H + c), bv = *(const u32x4*)(b + t * H + c);
+    u32x4 oa, ob;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dl = bflo(dv[k]), dh = bfhi(dv[k]);
+      s0 += dl * bflo(av[k]) + dh * bfhi(av[k]);
+      s1 += dl * bflo(bv[k]) + dh * bfhi(bv[k]);
+      oa[k] = pack2bf(dl * p0, dh * p0);
+      ob[k] = pack2bf(dl * p1, dh * p1);
+    }
+    *(u32x4*)(da + t * H + c) = oa;
+    *(u32x4*)(db + t * H + c) = ob;
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if (lane == 0) {
+    const float dot = p0 * s0 + p1 * s1;
+    dc[t * 2] = p0 * (s0 - dot);
+    dc[t * 2 + 1] = p1 * (s1 - dot);
+  }
+}
+// dx[t, :] = sum_e dlogits[t, e] * w[e, :]   (the input gradient of a tiny fp32 linear: router-sized heads)
+__global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                                bf16_t* __restrict__ dx, int T, int H, int E) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float d[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) d[e] = (e < E) ? dl[t * E + e] : 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E) {
+        const f32x4 w0 = *(const f32x4*)(w + (long long)e * H + c), w1 = *(const f32x4*)(w + (long long)e * H + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += d[e] * w0[j]; acc[4 + j] += d[e] * w1[j]; }
+      }
+    }
+    *(u32x4*)(dx + t * H + c) = (u32x4){pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+  }
+}
+
 extern "C" {
 
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream) {
@@ -455,25 +644,43 @@ int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, in
   return lmod_launch_status();
 }
 
-// Full gating decision from logits.  noise: [T,E] additive (Gumbel) noise for the 2nd pick, or NULL.
+// Full gating decision from logits.
+// noise / noise_mode: k == 2: additive [T,E] noise for the 2nd pick (Gumbel in the reference) — supplied (mode 0, may be
+//   NULL = no noise) or drawn in the kernel from (seed, offset) (mode 1).  k == 1: random-token-selection priorities
+//   (uniform in the reference, use_rts=True): supplied [T,E] (mode 0; NULL = token order, use_rts=False) or drawn (mode 2).
+//   noise_out (nullable, [T,E]): receives the drawn noise.
 // Outputs: gates[T,E] f32; idx1/idx2/slot1/slot2 [T] i32; w1/w2 [T] f32; slot_token [E*C] i32 (-1 empty);
 // slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.
-// scratch: 2*T + 24*ceil(T/512) i32 (loc1, loc2, per-block pick counts / bases and gate partial sums).
+// scratch: 4*T + 24*ceil(T/512) i32 (loc1, loc2, rts priorities / kept picks, per-block pick counts / bases, gate partials).
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
-                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, hipStream_t stream) {
+                  int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, int noise_mode,
+                  unsigned long long seed, unsigned long long offset, float* noise_out, hipStream_t stream) {
   if (!logits || !gates || !idx1 || !slot1 || !w1 || !slot_token || !slot_w || !exp_counts || !gate_sum || !l_aux ||
       !slots_used || !scratch || T <= 0 || E <= 0 || E > MAXE || (k != 1 && k != 2) || C <= 0) return LMOD_EINVAL;
   if (k == 2 && (!idx2 || !slot2 || !w2)) return LMOD_EINVAL;
+  if (noise_mode < 0 || noise_mode > 2 || (noise_mode == 1 && k != 2) || (noise_mode == 2 && k != 1)) return LMOD_EINVAL;
   int* loc1 = scratch; int* loc2 = scratch + T;
+  float* prio = (float*)(scratch + 2 * (long long)T);
+  int* keep = scratch + 3 * (long long)T;
   const int nb = (T + SCAN_BLK - 1) / SCAN_BLK;
-  int* part = scratch + 2 * (long long)T;                       // [nb][2*MAXE] ints
+  int* part = scratch + 4 * (long long)T;                       // [nb][2*MAXE] ints
   float* gpart = (float*)(part + (long long)nb * 2 * MAXE);     // [nb][MAXE] floats
-  hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k);
+  const bool rts = (k == 1) && (noise != nullptr || noise_mode == 2);
+  hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k,
+                     noise_mode, seed, offset, noise_out, rts ? prio : (float*)nullptr);
   hipLaunchKernelGGL(moe_count_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, gates, part, gpart, T, E, k);
   hipLaunchKernelGGL(moe_bases_kernel, dim3(1), dim3(64), 0, stream, part, gpart, nb, exp_counts, gate_sum, l_aux, slots_used,
                      T, E, k, C);
-  hipLaunchKernelGGL(moe_rank_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, part, loc1, loc2, T, k);
+  const int* rank_idx = idx1;
+  if (rts) {       // survivors of the random token selection, then their token-order positions (statistics stay as above)
+    hipLaunchKernelGGL(rts_select_kernel, dim3(E), dim3(1024), 0, stream, idx1, prio, keep, T, C);
+    hipLaunchKernelGGL(moe_count_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, keep, idx2, gates, part, gpart, T, E, k);
+    hipLaunchKernelGGL(moe_bases_kernel, dim3(1), dim3(64), 0, stream, part, gpart, nb, (int*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (int*)nullptr, T, E, k, C);
+    rank_idx = keep;
+  }
+  hipLaunchKernelGGL(moe_rank_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, rank_idx, idx2, part, loc1, loc2, T, k);
   if (hipMemsetAsync(slot_token, 0xFF, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   if (hipMemsetAsync(slot_w, 0, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   hipLaunchKernelGGL(moe_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, loc1, loc2,
@@ -534,6 +741,34 @@ int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float
                      dlogits, workspace, T, H, E);
   hipLaunchKernelGGL(router_wgrad_reduce_kernel, dim3((E * H + 63) / 64), dim3(1024), 0, stream, workspace, dwg, nslab,
                      E * H, accumulate);
+  return lmod_launch_status();
+}
+
+int lmod_moe_residual_mix_fwd(const void* moe_out, const void* mlp_out, const float* coef_logits, const float* coef_bias,
+                              void* out, float* p, int T, int H, hipStream_t stream) {
+  if (T < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  if (!moe_out || !mlp_out || !coef_logits || !coef_bias || !out || !p) return LMOD_EINVAL;
+  hipLaunchKernelGGL(residual_mix_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, (const bf16_t*)moe_out,
+                     (const bf16_t*)mlp_out, coef_logits, coef_bias, (bf16_t*)out, p, T, H);
+  return lmod_launch_status();
+}
+
+int lmod_moe_residual_mix_bwd(const void* dout, const void* moe_out, const void* mlp_out, const float* p, void* d_moe,
+                              void* d_mlp, float* d_coef_logits, int T, int H, hipStream_t stream) {
+  if (T < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  if (!dout || !moe_out || !mlp_out || !p || !d_moe || !d_mlp || !d_coef_logits) return LMOD_EINVAL;
+  hipLaunchKernelGGL(residual_mix_bwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, (const bf16_t*)dout,
+                     (const bf16_t*)moe_out, (const bf16_t*)mlp_out, p, (bf16_t*)d_moe, (bf16_t*)d_mlp, d_coef_logits, T, H);
+  return lmod_launch_status();
+}
+
+int lmod_small_linear_dgrad(const float* dlogits, const float* w, void* dx, int T, int H, int E, hipStream_t stream) {
+  if (T < 0 || H <= 0 || (H & 7) || E <= 0 || E > MAXE) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  if (!dlogits || !w || !dx || ((uintptr_t)w & 15)) return LMOD_EINVAL;
+  hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, dlogits, w, (bf16_t*)dx, T, H, E);
   return lmod_launch_status();
 }
 

@@ -39,12 +39,15 @@ SIGNATURES = {
     "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
     "lmod_moe_router_fwd": "ppp" + "iii" + "p",
-    "lmod_moe_gate": "pp" + "iiii" + "pppppppppppppp" + "p",
+    "lmod_moe_gate": "pp" + "iiii" + "pppppppppppppp" + "iQQp" + "p",
     "lmod_moe_combine_fwd": "pppppp" + "ii" + "p",
     "lmod_moe_combine_bwd": "ppppppppp" + "iii" + "p",
     "lmod_moe_gate_bwd": "pppppppppp" + "iii" + "p",
     "lmod_moe_dispatch_bwd": "pppppp" + "iii" + "p",
     "lmod_moe_router_wgrad": "pppp" + "iiii" + "p",
+    "lmod_moe_residual_mix_fwd": "pppp" + "pp" + "ii" + "p",
+    "lmod_moe_residual_mix_bwd": "pppp" + "ppp" + "ii" + "p",
+    "lmod_small_linear_dgrad": "ppp" + "iii" + "p",
     "lmod_rowloss_fwd": "pqi" + "pqi" + "pp" + "i" + "p",
     "lmod_rowloss_bwd": "pqi" + "pqi" + "pp" + "ppppp" + "pq" + "i" + "p",
     "lmod_segment_wsum": "pii" + "pp" + "i" + "pp" + "p",
@@ -52,7 +55,7 @@ SIGNATURES = {
     "lmod_rowdot_masked": "pp" + "ii" + "p" + "p",
     "lmod_dpo_loss": "pppp" + "iffi" + "ppppp" + "p",
 }
-_CT = {"p": _P, "i": _I, "q": _Q, "f": _F}
+_CT = {"p": _P, "i": _I, "q": _Q, "f": _F, "Q": ctypes.c_ulonglong}
 _ERR = {-1: "LMOD_EINVAL (bad pointer/shape/alignment)", -2: "LMOD_ELAUNCH (HIP launch error)",
         -3: "LMOD_EUNSUPPORTED (outside compiled envelope)"}
 

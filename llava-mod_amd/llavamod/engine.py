@@ -89,10 +89,10 @@ class GradBuffer:
             if p.requires_grad and id(p) not in covered:
                 # norm scales, the embedding table and the CLIP tower have no weight-gradient kernel on this path (the
                 # distillation shells freeze them: dense2sparse_distillation.sh train_modules); fail loudly, not silently
-                if not (n.endswith("wg.weight") or ".wg." in n):
+                if not (n.endswith("wg.weight") or "wg." in n or "coefficient." in n):
                     raise NotImplementedError(
                         f"parameter {n!r} is marked trainable but this path computes no gradient for it (supported: "
-                        f"attention / MLP / expert / projector / lm_head linears and the MoE router); freeze it or list "
+                        f"attention / MLP / expert / projector / lm_head linears, the MoE router and the Residual-MoE coefficient head); freeze it or list "
                         f"only supported modules in train_modules")
                 spans.append(("p", p, p.numel()))
                 covered.add(id(p))

@@ -276,10 +276,13 @@ def moe_router_fwd(x, wg):
 class GateState:
     """Index maps produced by lmod_moe_gate (all device tensors)."""
     __slots__ = ("T", "E", "k", "C", "gates", "idx1", "idx2", "slot1", "slot2", "w1", "w2", "slot_token", "slot_w",
-                 "exp_counts", "gate_sum", "l_aux", "slots_used")
+                 "exp_counts", "gate_sum", "l_aux", "slots_used", "noise")
 
 
-def moe_gate(logits, k, C, noise=None):
+def moe_gate(logits, k, C, noise=None, seed=None, offset=0, want_noise=False):
+    """noise: explicit [T,E] noise (k=2: added for the 2nd pick; k=1: random-token-selection priorities).  seed (with noise
+    None): the kernel draws it (Gumbel for k=2, uniform for k=1) from Philox(seed, offset + token); want_noise returns it as
+    st.noise."""
     T, E = logits.shape
     dev = logits.device
     st = GateState()
@@ -295,10 +298,13 @@ def moe_gate(logits, k, C, noise=None):
     st.slot_token = torch.empty(E * C, **i32); st.slot_w = torch.empty(E * C, **f32)
     st.exp_counts = torch.empty(E, **i32); st.gate_sum = torch.empty(E, **f32); st.l_aux = torch.empty(1, **f32)
     st.slots_used = torch.empty(E, **i32)
-    scratch = torch.empty(2 * T + 24 * ((T + 511) // 512), **i32)
+    scratch = torch.empty(4 * T + 24 * ((T + 511) // 512), **i32)
+    mode = 0 if (noise is not None or seed is None) else (1 if k == 2 else 2)
+    st.noise = torch.empty((T, E), **f32) if (mode and want_noise) else None
     call("lmod_moe_gate", ptr(logits), ptr(noise), T, E, k, C, ptr(st.gates), ptr(st.idx1), ptr(st.idx2),
          ptr(st.slot1), ptr(st.slot2), ptr(st.w1), ptr(st.w2), ptr(st.slot_token), ptr(st.slot_w),
-         ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(st.slots_used), ptr(scratch))
+         ptr(st.exp_counts), ptr(st.gate_sum), ptr(st.l_aux), ptr(st.slots_used), ptr(scratch), mode,
+         int(seed or 0) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFFFFFFFFFF, ptr(st.noise))
     return st
 
 
@@ -338,6 +344,30 @@ def moe_router_wgrad(x, dlogits, dwg, accumulate):
     ws = torch.empty(((T + 63) // 64) * E * H, device=x.device, dtype=torch.float32)      # one partial per 64-token slab
     call("lmod_moe_router_wgrad", ptr(x), ptr(dlogits), ptr(dwg), ptr(ws), T, H, E, int(accumulate))
     return dwg
+
+
+def residual_mix_fwd(moe_out, mlp_out, coef_logits, coef_bias):
+    T, H = moe_out.shape
+    out = torch.empty_like(moe_out)
+    p = torch.empty((T, 2), device=moe_out.device, dtype=torch.float32)
+    call("lmod_moe_residual_mix_fwd", ptr(moe_out), ptr(mlp_out), ptr(coef_logits), ptr(coef_bias), ptr(out), ptr(p), T, H)
+    return out, p
+
+
+def residual_mix_bwd(dout, moe_out, mlp_out, p):
+    T, H = moe_out.shape
+    d_moe, d_mlp = torch.empty_like(moe_out), torch.empty_like(moe_out)
+    dc = torch.empty((T, 2), device=moe_out.device, dtype=torch.float32)
+    call("lmod_moe_residual_mix_bwd", ptr(dout), ptr(moe_out), ptr(mlp_out), ptr(p), ptr(d_moe), ptr(d_mlp), ptr(dc), T, H)
+    return d_moe, d_mlp, dc
+
+
+def small_linear_dgrad(dlogits, w):
+    T, E = dlogits.shape
+    H = w.shape[1]
+    dx = torch.empty((T, H), device=dlogits.device, dtype=BF16)
+    call("lmod_small_linear_dgrad", ptr(dlogits), ptr(w), ptr(dx), T, H, E)
+    return dx
 
 
 # ------------------------------------------------------------------------------------------ losses

@@ -53,8 +53,6 @@ class MoE(nn.Module):
             raise ValueError(f"Number of experts ({num_experts}) should be divisible by expert parallel size ({ep_size})")
         if num_experts > 8:
             raise NotImplementedError("the routing kernels are compiled for <= 8 experts")
-        if use_residual:
-            raise NotImplementedError("use_residual (Residual-MoE) is not on the distillation hot path")
         self.hidden_size, self.num_experts, self.ep_size, self.k = hidden_size, num_experts, ep_size, k
         self.capacity_factor, self.eval_capacity_factor, self.min_capacity = capacity_factor, eval_capacity_factor, min_capacity
         self.use_rts = use_rts
@@ -65,10 +63,34 @@ class MoE(nn.Module):
         self._gu = FusedWeight([[e.gate_proj.weight, e.up_proj.weight] for e in ex])
         self._down = FusedWeight([[e.down_proj.weight] for e in ex])
         self._gu.is_expert = self._down.is_expert = True        # engine: not all-reduced across the EP group
+        self.use_residual = use_residual
+        if use_residual:            # Residual-MoE (layer.MoE.__init__): a dense copy of the expert + a 2-way mixing head
+            self.mlp = copy.deepcopy(expert)
+            self.coefficient = nn.Linear(hidden_size, 2, device=device, dtype=next(expert.parameters()).dtype)
         self.ep_group = None        # torch.distributed group of size ep_size (engine.expert_parallel_group)
         self.force_decomposed = False   # tests: run the EP code path with ep_size == 1 (identity exchange)
-        self.gate_noise = None     # explicit [T, E] Gumbel noise for the next top-2 forward (None: sampled)
-        self.deterministic = False  # True: no noise at all (parity tests)
+        # Gating noise.  Reference: top-2 adds Gumbel noise to the logits for the 2nd pick (gumbel_rsample); top-1 with
+        # use_rts=True (the DeepSpeed default) draws uniform priorities for random token selection.  Here both are drawn
+        # INSIDE the gating kernel (Philox keyed by torch's seed, this layer's id and a call counter): no torch math on the
+        # MoE path.  gate_noise: explicit [T, E] noise for the next forward instead (parity tests feed the oracle the same).
+        self.gate_noise = None
+        self.deterministic = False  # True: no noise at all (top-2: plain 2nd argmax; top-1: token-order selection)
+        MoE._LAYERS[0] += 1
+        self._layer_id = MoE._LAYERS[0]
+        self._calls = 0
+
+    _LAYERS = [0]
+
+    def _noise(self, T, device):
+        """(explicit noise tensor or None, Philox seed or None, counter offset) of this forward."""
+        if self.deterministic or (self.k == 1 and not self.use_rts):
+            return None, None, 0
+        if self.gate_noise is not None:
+            return self.gate_noise.to(device=device, dtype=torch.float32).contiguous(), None, 0
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._layer_id * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        off = self._calls * (1 << 24)            # a fresh counter range per call (T < 2^24 tokens)
+        self._calls += 1
+        return None, seed, off
 
     def capacity(self, T):
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
@@ -87,20 +109,19 @@ class MoE(nn.Module):
         x = hidden_states.reshape(-1, shp[-1])
         T = x.shape[0]
         wg = self.deepspeed_moe.gate.wg.weight
-        noise = None
-        if self.k == 2 and not self.deterministic:
-            if self.gate_noise is not None:
-                noise = self.gate_noise.to(device=x.device, dtype=torch.float32).contiguous()
-            else:   # gumbel_rsample of sharded_moe.top2gating
-                u = torch.rand((T, self.num_experts), device=x.device).clamp_(1e-20, 1.0)
-                noise = -torch.log(-torch.log(u))
+        noise, seed, off = self._noise(T, x.device)
         spec = SimpleNamespace(E=self.num_experts, k=self.k, capacity=self.capacity, wg=wg,
-                               gu=self._gu.ensure(), down=self._down.ensure())
+                               gu=self._gu.ensure(), down=self._down.ensure(), seed=seed, offset=off)
+        expert_side = [q for q in self.deepspeed_moe.parameters() if q.requires_grad]
         if self.ep_size == 1 and not self.force_decomposed:
-            out, l_aux, counts = ops.MoEBlock.apply(x, spec, noise, *self.trainable())
+            out, l_aux, counts = ops.MoEBlock.apply(x, spec, noise, *expert_side)
         else:
             out, l_aux, counts = self._forward_expert_parallel(x, spec, noise)
         self.last_state = spec.last_state          # routing maps of this call (inspection / tests)
+        if self.use_residual:                      # out * coef[..., 0:1] + mlp(x) * coef[..., 1:]  (layer.MoE.forward)
+            res = self.mlp(x)
+            cw = [q for q in self.coefficient.parameters() if q.requires_grad]
+            out = ops.ResidualMix.apply(out, res, x, self.coefficient, *cw)
         return out.reshape(shp), l_aux.reshape(()), counts
 
     def _forward_expert_parallel(self, x, spec, noise):

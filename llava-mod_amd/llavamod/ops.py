@@ -380,7 +380,7 @@ class MoEBlock(torch.autograd.Function):
         T, H = x.shape
         E, C, k = spec.E, spec.capacity(T), spec.k
         logits = K.moe_router_fwd(x, spec.wg.data)
-        st = K.moe_gate(logits, k, C, noise)
+        st = K.moe_gate(logits, k, C, noise, seed=getattr(spec, "seed", None), offset=getattr(spec, "offset", 0))
         rows = st.slots_used
         disp = K.gather_rows(x, None, st.slot_token, H)                       # [E*C, H], zero rows on empty slots
         I = spec.gu.w.shape[1] // 2
@@ -438,6 +438,38 @@ class MoEBlock(torch.autograd.Function):
             K.moe_router_wgrad(x, dlogits, sp.wg.main_grad, True)
         dx = K.moe_dispatch_bwd(d_in.view(E * C, H), st, dlogits, sp.wg.data, H)
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class ResidualMix(torch.autograd.Function):
+    """Residual-MoE output mix (deepspeed.moe.layer.MoE.forward with use_residual): coef = softmax(coefficient(x)),
+    out = moe_out * coef[..., 0:1] + mlp_out * coef[..., 1:].  The 2-wide `coefficient` head runs on the router kernels
+    (fp32 dot products, E = 2); its parameters take fp32 main_grads like the router's."""
+
+    @staticmethod
+    def forward(ctx, moe_out, mlp_out, x, coef, *params):
+        w32 = coef.weight.detach().float().contiguous()
+        b32 = (coef.bias.detach().float() if coef.bias is not None else torch.zeros(2, device=x.device)).contiguous()
+        clog = K.moe_router_fwd(x, w32)
+        out, p = K.residual_mix_fwd(moe_out.contiguous(), mlp_out.contiguous(), clog, b32)
+        ctx.coef = coef
+        ctx.save_for_backward(moe_out, mlp_out, x, p, w32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        moe_out, mlp_out, x, p, w32 = ctx.saved_tensors
+        coef = ctx.coef
+        d_moe, d_mlp, dc = K.residual_mix_bwd(dout.contiguous(), moe_out, mlp_out, p)
+        if coef.weight.requires_grad:
+            if getattr(coef.weight, "main_grad", None) is None:
+                coef.weight.main_grad = torch.zeros(coef.weight.shape, device=x.device, dtype=torch.float32)
+            K.moe_router_wgrad(x, dc, coef.weight.main_grad, True)
+        if coef.bias is not None and coef.bias.requires_grad:
+            if getattr(coef.bias, "main_grad", None) is None:
+                coef.bias.main_grad = torch.zeros(2, device=x.device, dtype=torch.float32)
+            coef.bias.main_grad.add_(dc.sum(0))                 # [T, 2] -> [2]: scalar-sized glue
+        dx = K.small_linear_dgrad(dc, w32)
+        return (d_moe, d_mlp, dx, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 # ------------------------------------------------------------------------------------------ loss head
@@ -530,7 +562,7 @@ class MoERoute(torch.autograd.Function):
         T, H = x.shape
         C = spec.capacity(T)
         logits = K.moe_router_fwd(x, spec.wg.data)
-        st = K.moe_gate(logits, spec.k, C, noise)
+        st = K.moe_gate(logits, spec.k, C, noise, seed=getattr(spec, "seed", None), offset=getattr(spec, "offset", 0))
         disp = K.gather_rows(x, None, st.slot_token, H)
         ctx.spec, ctx.st, ctx.H = spec, st, H
         spec.last_state = st

@@ -18,6 +18,8 @@ def _header_decls():
             p = p.strip()
             if "hipStream_t" in p or "*" in p:
                 sig += "p"
+            elif p.startswith("unsigned long long"):
+                sig += "Q"
             elif p.startswith("long long"):
                 sig += "q"
             elif p.startswith("float"):

@@ -708,3 +708,102 @@ def test_sumsq_clip_cast_and_adamw_device_scale():
     xf = torch.empty_like(x)
     K.cast_f32_bf16(xb, xf)
     assert torch.equal(xf, xb.float())
+
+
+def _dense_from_state(st, T, E, C):
+    dense = torch.zeros(T, E * C, device=DEV)
+    for slot, w in ((st.slot1, st.w1),) + (((st.slot2, st.w2),) if st.k == 2 else ()):
+        keep = slot >= 0
+        dense[torch.nonzero(keep).squeeze(1), slot[keep].long()] = w[keep]
+    return dense.reshape(T, E, C)
+
+
+def test_moe_gate_noise_drawn_in_kernel():
+    """Philox noise drawn inside the gating kernel: Gumbel(0,1) statistics (mean = Euler's gamma, var = pi^2/6),
+    reproducible from (seed, offset), different per offset, and the picks are exactly those of a second call that is FED the
+    drawn noise (so the oracle, given the same tensor, reproduces the routing)."""
+    T, E = 8192, 4
+    logits = torch.randn(T, E, generator=torch.Generator().manual_seed(1)).to(DEV)
+    C = omoe.capacity(T, E, 1.5 * 2, 0)
+    a = K.moe_gate(logits, 2, C, None, seed=1234, offset=77, want_noise=True)
+    b = K.moe_gate(logits, 2, C, None, seed=1234, offset=77, want_noise=True)
+    c = K.moe_gate(logits, 2, C, None, seed=1234, offset=77 + (1 << 24), want_noise=True)
+    assert torch.equal(a.noise, b.noise) and torch.equal(a.idx2, b.idx2) and not torch.equal(a.noise, c.noise)
+    n = a.noise.double()
+    assert abs(n.mean().item() - 0.5772) < 0.03 and abs(n.var().item() - math.pi ** 2 / 6) < 0.08
+    assert torch.isfinite(a.noise).all()
+    fed = K.moe_gate(logits, 2, C, a.noise)
+    assert torch.equal(fed.idx1, a.idx1) and torch.equal(fed.idx2, a.idx2) and torch.equal(fed.slot2, a.slot2)
+    _, combine, _, _ = omoe.top2gating(logits, 1.5, 0, a.noise)
+    close(_dense_from_state(a, T, E, C), combine, "combine with in-kernel noise", rtol=1e-5, afrac=1e-6)
+    u = K.moe_gate(logits, 1, omoe.capacity(T, E, 1.0, 0), None, seed=5, offset=0, want_noise=True).noise
+    assert 0.0 < u.min().item() and u.max().item() < 1.0 and abs(u.mean().item() - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("T,E,cf", [(1000, 4, 1.0), (4096, 8, 0.5), (300, 4, 4.0)])
+def test_moe_gate_top1_random_token_selection(T, E, cf):
+    """top1gating with use_rts (DeepSpeed's default): per expert the C tokens with the largest uniform priority keep their
+    slot, survivors are numbered in token order; l_aux / exp_counts see every token.  Against the oracle's restatement,
+    with explicit priorities, incl. an exact tie at the capacity boundary."""
+    g = torch.Generator().manual_seed(T)
+    logits = torch.randn(T, E, generator=g).to(DEV)
+    prio = torch.rand(T, E, generator=g).to(DEV)
+    C = omoe.capacity(T, E, cf, 0)
+    st = K.moe_gate(logits, 1, C, prio)
+    l_aux, combine, dispatch, counts = omoe.top1gating(logits, cf, 0, prio)
+    close(_dense_from_state(st, T, E, C), combine, "rts combine", rtol=1e-5, afrac=1e-6)
+    assert torch.equal(st.exp_counts.long(), counts.long())
+    close(st.l_aux, l_aux.reshape(1), "rts l_aux", rtol=1e-5, afrac=1e-7)
+    assert int((st.slot_token >= 0).sum()) == int(dispatch.sum())
+    # token order (use_rts=False) through the same entry point
+    st0 = K.moe_gate(logits, 1, C, None)
+    _, combine0, _, _ = omoe.top1gating(logits, cf, 0, None)
+    close(_dense_from_state(st0, T, E, C), combine0, "token-order combine", rtol=1e-5, afrac=1e-6)
+    # ties exactly at the boundary: every token of expert 0 has the same priority -> the first C in token order survive
+    prio2 = prio.clone()
+    prio2[:, 0] = 0.25
+    st2 = K.moe_gate(logits, 1, C, prio2)
+    kept = torch.nonzero((st2.idx1 == 0) & (st2.slot1 >= 0)).squeeze(1)
+    allt = torch.nonzero(st2.idx1 == 0).squeeze(1)
+    assert torch.equal(kept, allt[:min(C, allt.numel())])
+
+
+def test_residual_moe_layer_vs_oracle():
+    """deepspeed.moe.layer.MoE(use_residual=True): out = moe(x) * c0 + mlp(x) * c1, (c0, c1) = softmax(coefficient(x)).
+    The HIP layer against the oracle's layer on the same weights and routing noise: output, l_aux and every gradient."""
+    import copy
+    from oracle.decoder import MLP as OMLP, DecoderConfig
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
+    from llavamod.model.moe_layer import MoE
+    H, I, E, T = 256, 512, 4, 384
+    cfg = Qwen2Config(hidden_size=H, intermediate_size=I, num_hidden_layers=1, num_attention_heads=2, vocab_size=64)
+    expert = init_normal_(Qwen2MLP(cfg, DEV), 0.05, 3)
+    layer = MoE(H, expert, num_experts=E, k=2, capacity_factor=1.5, min_capacity=0, use_residual=True)
+    init_normal_(layer, 0.05, 4)                                   # experts / residual mlp / coefficient all different
+    ocfg = DecoderConfig(vocab_size=64, hidden_size=H, intermediate_size=I, num_hidden_layers=1, num_attention_heads=2,
+                         num_key_value_heads=2)
+    olayer = omoe.OracleMoE(H, OMLP(ocfg), num_experts=E, k=2, capacity_factor=1.5, min_capacity=0, use_residual=True)
+    sd = {k: v.detach().float().cpu() for k, v in layer.state_dict().items()}
+    assert set(sd) == set(olayer.state_dict()), sorted(set(sd) ^ set(olayer.state_dict()))
+    olayer.load_state_dict(sd)
+    x = rnd(T, H, seed=9, scale=1.0)
+    noise = omoe.gumbel_noise((T, E), torch.Generator().manual_seed(2))
+    layer.train(); olayer.train()
+    layer.gate_noise = noise
+    olayer.noise = noise
+    for p in layer.parameters():
+        p.requires_grad_(True)
+    from llavamod.engine import GradBuffer
+    GradBuffer(layer)
+    xh = x.clone().requires_grad_(True)
+    out, l_aux, counts = layer(xh)
+    dout = rnd(T, H, seed=10)
+    ((out.float() * dout.float()).sum() + 3.0 * l_aux).backward()
+    xo = x.float().cpu().requires_grad_(True)
+    oo, ol, oc = olayer(xo)
+    ((oo * dout.float().cpu()).sum() + 3.0 * ol).backward()
+    close(out, oo.to(DEV), "residual moe out", rtol=2 ** -6, afrac=2 ** -7)
+    close(l_aux.reshape(1), ol.reshape(1).to(DEV), "residual moe l_aux", rtol=1e-4, afrac=1e-6)
+    close(xh.grad, xo.grad.to(DEV), "residual moe dx", rtol=2 ** -5, afrac=2 ** -6)
+    for (n, p), (_, po) in zip(layer.named_parameters(), olayer.named_parameters()):
+        close(p.main_grad, po.grad.to(DEV), f"residual moe grad {n}", rtol=2 ** -5, afrac=2 ** -5)

@@ -352,6 +352,8 @@ def test_finetune_student_and_top1_step():
         m.rts_noise = None                                      # token order
     loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, ob, loss_type="kd_lm", align_vocab=512)
     s1, t1 = U.build_hip_pair(ssd, tsd, sc1, tc, vc, DEV)
+    for m in s1.moe_layers():
+        m.deterministic = True                                  # token order (random token selection: kernel tests)
     GradBuffer(s1)
     tr = AlignTrainer(s1, t1, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False, loss_type="kd_lm",
                                                       moe_loss_enable=True))(), align_vocab=512)
