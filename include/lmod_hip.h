@@ -146,6 +146,15 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
                   int causal, hipStream_t stream);
 
+/* Single-query attention against a KV cache (generation: llava_qwen2_moe.py:453-473 prepare_inputs_for_generation,
+ * qwen2/modeling_qwen2.py:290-309 with q_len 1).  q [B, ldq] (head h at column h*hd), caches [B, smax, ld_cache] (kv head
+ * at column hk*hd, keys 0 .. lens[b]-1 valid, the new token's key/value already appended), out [B, ldo]. */
+int lmod_attn_decode(const void* q, const void* kcache, const void* vcache, const int* lens, void* out, int B, int nh,
+                     int nkv, int hd, int smax, int ldq, int ld_cache, int ldo, float scale, hipStream_t stream);
+
+/* Greedy decoding: out[r] = argmax_v logits[r, v] over bf16 rows (first maximum wins). */
+int lmod_row_argmax_bf16(const void* logits, long long ld, int V, int* out, int R, hipStream_t stream);
+
 /* ---- sparse MoE (DeepSpeed 0.9.5 TopKGate/top1gating/top2gating/MOELayer semantics) ------------
  * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32). */
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);

@@ -705,3 +705,92 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
 }
 
 }  // extern "C"
+
+// ============================================================================ single-query (decode) attention
+// Generation with a KV cache (reference: llava_qwen2_moe.py:453-473 prepare_inputs_for_generation + HF generate;
+// qwen2/modeling_qwen2.py:290-309 with q_len == 1).  One workgroup per (batch sample, query head): the new token's
+// query against lens[b] cached keys.  HBM-bound: K and V of the head are read once.
+//   phase 1: thread <-> key (256 keys per chunk): full dot product with the query (q broadcast from LDS), scores to LDS,
+//            running max / sum over chunks (online softmax, fp32);
+//   phase 2: thread <-> (feature pair, key slice): p-weighted sum of the chunk's V rows, coalesced 4-byte loads.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                         const bf16_t* __restrict__ vc, const int* __restrict__ lens,
+                                                         bf16_t* __restrict__ out, int nh, int group, int smax, int ldq,
+                                                         int ldc, int ldo, float scale) {
+  __shared__ float sq[HD];
+  __shared__ float sp[256];
+  __shared__ float red[8];
+  __shared__ float oacc[256 / (HD / 2)][HD];      // one partial per key slice
+  const int h = blockIdx.x, b = blockIdx.y, hk = h / group, tid = threadIdx.x;
+  const int len = min(lens[b], smax);
+  if (tid < HD) sq[tid] = bf2f(q[(long long)b * ldq + h * HD + tid]) * scale;
+  __syncthreads();
+  const bf16_t* kb = kc + (long long)b * smax * ldc + hk * HD;
+  const bf16_t* vb = vc + (long long)b * smax * ldc + hk * HD;
+  constexpr int DP = HD / 2;                 // feature pairs; thread owns pair tid % DP in key slice tid / DP
+  constexpr int NSL = 256 / DP;              // key slices per chunk (4 at hd 128, 8 at hd 64)
+  const int dp = tid % DP, sl = tid / DP;
+  float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const int key = c0 + tid;
+    float s = -INFINITY;
+    if (key < len) {
+      const bf16_t* kr = kb + (long long)key * ldc;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 8) {
+        const u32x4 w = *(const u32x4*)(kr + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a += bflo(w[j]) * sq[d + 2 * j] + bfhi(w[j]) * sq[d + 2 * j + 1];
+      }
+      s = a;
+    }
+    const float cm = block_max<4>(s, red);
+    const float mnew = fmaxf(m, cm);
+    const float alpha = (mnew == -INFINITY) ? 1.f : __expf(m - mnew);
+    const float p = (key < len) ? __expf(s - mnew) : 0.f;
+    const float cs = block_sum<4>(p, red);
+    l = l * alpha + cs;
+    m = mnew;
+    o0 *= alpha; o1 *= alpha;
+    __syncthreads();
+    sp[tid] = p;
+    __syncthreads();
+    const int nk = min(256, len - c0);
+    for (int kk = sl; kk < nk; kk += NSL) {
+      const uint32_t w = *(const uint32_t*)(vb + (long long)(c0 + kk) * ldc + dp * 2);
+      const float pv = sp[kk];
+      o0 += pv * bflo(w); o1 += pv * bfhi(w);
+    }
+  }
+  __syncthreads();
+  float* oa = &oacc[0][0];                   // [NSL][HD] partial sums of the key slices (4 x 128 or 8 x 64 floats)
+  oa[sl * HD + dp * 2] = o0; oa[sl * HD + dp * 2 + 1] = o1;
+  __syncthreads();
+  if (tid < HD) {
+    float acc = 0.f;
+#pragma unroll
+    for (int x = 0; x < NSL; ++x) acc += oa[x * HD + tid];
+    out[(long long)b * ldo + h * HD + tid] = f2bf(l > 0.f ? acc / l : 0.f);
+  }
+}
+
+extern "C" int lmod_attn_decode(const void* q, const void* kcache, const void* vcache, const int* lens, void* out, int B,
+                                int nh, int nkv, int hd, int smax, int ldq, int ld_cache, int ldo, float scale,
+                                hipStream_t stream) {
+  if (B < 0 || nh <= 0 || nkv <= 0 || nh % nkv || smax <= 0) return LMOD_EINVAL;
+  if (B == 0) return LMOD_OK;
+  if (!q || !kcache || !vcache || !lens || !out) return LMOD_EINVAL;
+  if (hd != 64 && hd != 128) return LMOD_EUNSUPPORTED;
+  if ((ld_cache & 7) || ld_cache < nkv * hd || ldq < nh * hd || ldo < nh * hd || ((uintptr_t)kcache & 15) || ((uintptr_t)vcache & 15))
+    return LMOD_EINVAL;
+  const dim3 grid(nh, B);
+  if (hd == 128)
+    hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)kcache,
+                       (const bf16_t*)vcache, lens, (bf16_t*)out, nh, nh / nkv, smax, ldq, ld_cache, ldo, scale);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)kcache,
+                       (const bf16_t*)vcache, lens, (bf16_t*)out, nh, nh / nkv, smax, ldq, ld_cache, ldo, scale);
+  return lmod_launch_status();
+}

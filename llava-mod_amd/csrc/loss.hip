@@ -261,6 +261,30 @@ __global__ __launch_bounds__(256) void rowdot_masked_kernel(const float* __restr
   if (threadIdx.x == 0) x[row] = a;
 }
 
+// ---------------------------------------------------------------- greedy decoding: argmax over a logits row
+// (first maximum wins, like torch.argmax on ties in practice; NaN never wins)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const bf16_t* __restrict__ x, long long ld, int V, int* __restrict__ out) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const bf16_t* r = x + (long long)blockIdx.x * ld;
+  float best = -INFINITY; int idx = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float v = bf2f(r[c]);
+    if (v > best) { best = v; idx = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out[blockIdx.x] = (idx == 0x7fffffff) ? 0 : idx;
+  }
+}
+
 extern "C" {
 
 int lmod_rowloss_fwd(const void* s, long long ld_s, int Vs, const void* t, long long ld_t, int Va,
@@ -318,6 +342,14 @@ int lmod_rowdot_masked(const float* p, const float* logp, int V, int R, float* x
   if (!p || !logp || !x || R < 0 || V <= 0) return LMOD_EINVAL;
   if (R == 0) return LMOD_OK;
   hipLaunchKernelGGL(rowdot_masked_kernel, dim3(R), dim3(256), 0, stream, p, logp, V, x);
+  return lmod_launch_status();
+}
+
+int lmod_row_argmax_bf16(const void* logits, long long ld, int V, int* out, int R, hipStream_t stream) {
+  if (R < 0 || V <= 0 || ld < V) return LMOD_EINVAL;
+  if (R == 0) return LMOD_OK;
+  if (!logits || !out) return LMOD_EINVAL;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(R), dim3(256), 0, stream, (const bf16_t*)logits, ld, V, out);
   return lmod_launch_status();
 }
 

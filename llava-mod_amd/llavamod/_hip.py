@@ -38,6 +38,8 @@ SIGNATURES = {
     "lmod_cast_f32_bf16": "pp" + "qi" + "p",
     "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
+    "lmod_row_argmax_bf16": "pqi" + "pi" + "p",
+    "lmod_attn_decode": "ppppp" + "iiiiiiii" + "f" + "p",
     "lmod_moe_router_fwd": "ppp" + "iii" + "p",
     "lmod_moe_gate": "pp" + "iiii" + "pppppppppppppp" + "iQQp" + "p",
     "lmod_moe_combine_fwd": "pppppp" + "ii" + "p",

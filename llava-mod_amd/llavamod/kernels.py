@@ -264,6 +264,22 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, 
     return dq, dk, dv
 
 
+def row_argmax(logits):
+    R, V = logits.shape
+    out = torch.empty(R, device=logits.device, dtype=torch.int32)
+    call("lmod_row_argmax_bf16", ptr(logits), logits.stride(0), V, ptr(out), R)
+    return out
+
+
+def attn_decode(q, kcache, vcache, lens, nh, nkv, hd, scale):
+    """q [B, nh*hd] (views fine), caches [B, Smax, nkv*hd] with lens[b] valid keys -> out [B, nh*hd]."""
+    B = q.shape[0]
+    out = torch.empty((B, nh * hd), device=q.device, dtype=BF16)
+    call("lmod_attn_decode", ptr(q), ptr(kcache), ptr(vcache), ptr(lens), ptr(out), B, nh, nkv, hd, kcache.shape[1],
+         q.stride(0), kcache.stride(1), out.stride(0), float(scale))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ MoE
 def moe_router_fwd(x, wg):
     T, H = x.shape

@@ -16,7 +16,7 @@ from ...constants import IGNORE_INDEX
 from ...ops import FusedWeight
 from ..llava_arch import LlavaMetaForCausalLM, LlavaMetaModel
 from ..utils import CausalLMOutputWithPast
-from .qwen2_hip import Qwen2Config, Qwen2Model, _Linear, init_normal_
+from .qwen2_hip import KVCache, Qwen2Config, Qwen2Model, _Linear, init_normal_
 
 BF16 = torch.bfloat16
 
@@ -119,6 +119,141 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
                                       inv_rows=inv_rows)
         return hidden, moe_list, info
 
+    # ---- generation (KV cache) -------------------------------------------------------------------------------------
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, attention_mask=None, **kwargs):
+        """HF contract of the reference (llava_qwen2_moe.py:453-473): after the first step only the last token is fed and the
+        images are dropped; `images` rides along on the first step."""
+        images = kwargs.pop("images", None)
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        model_inputs = {"inputs_embeds": inputs_embeds} if (inputs_embeds is not None and past_key_values is None) \
+            else {"input_ids": input_ids}
+        model_inputs.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache", True),
+                             "attention_mask": attention_mask})
+        if images is not None and past_key_values is None:
+            model_inputs["images"] = images
+        return model_inputs
+
+    @torch.no_grad()
+    def _prefill(self, input_ids, attention_mask, images, max_new_tokens):
+        """Splice + full forward storing K/V; returns (cache, bf16 logits [B, V] of each sample's LAST valid position)."""
+        _, _, am, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None, images)
+        dev = self.model.embed_tokens.weight.device
+        if embeds is None:
+            B, S = input_ids.shape
+            idx = input_ids.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+            embeds = K.gather_rows(self.model.embed_tokens.weight, None, idx, self.model.embed_tokens.weight.shape[1]).view(B, S, -1)
+            am = attention_mask
+        B, S, H = embeds.shape
+        lens = (am.to(device=dev).to(torch.int32).sum(1) if am is not None else torch.full((B,), S, device=dev)).to(torch.int32)
+        seqlens = lens.contiguous() if bool((lens != S).any()) else None
+        cfg = self.config
+        cache = KVCache(cfg.num_hidden_layers, B, S + max_new_tokens, cfg.num_key_value_heads * cfg.head_dim, dev)
+        rows = (torch.arange(B, device=dev, dtype=torch.int32) * S + lens - 1).to(torch.int32).contiguous()
+        inv = torch.full((B * S,), -1, device=dev, dtype=torch.int32)
+        inv[rows.long()] = torch.arange(B, device=dev, dtype=torch.int32)
+        hidden, _ = self.model(embeds.reshape(B * S, H), B, S, seqlens, out_rows=rows, inv_rows=inv, cache=cache)
+        cache.lens.copy_(lens)
+        return cache, ops.linear_fwd(hidden, self.head())
+
+    generation_budget = 512            # cache positions reserved beyond the prompt by a `use_cache=True` forward
+
+    @torch.no_grad()
+    def _cached_forward(self, input_ids, attention_mask, images, past, out_cls):
+        """`forward(..., use_cache=True / past_key_values=...)` as HF's generation loop drives it: the first call prefills
+        and returns the cache, later calls feed the last token.  logits: [B, 1, V] fp32 (the last position only)."""
+        if past is None:
+            cache, logits = self._prefill(input_ids, attention_mask, images, self.generation_budget)
+        else:
+            cache = past
+            if int(cache.lens.max()) >= cache.smax:
+                raise ValueError("KV cache exhausted: raise `generation_budget` before the prefill")
+            dev = cache.lens.device
+            logits = self._decode_step(input_ids[:, -1].to(device=dev, dtype=torch.int32), cache)
+        return out_cls(loss=None, logits=logits.float().unsqueeze(1), past_key_values=cache)
+
+    @torch.no_grad()
+    def _decode_step(self, tokens, cache):
+        """tokens [B] (device int32) -> bf16 logits [B, V] of the next position."""
+        emb = K.gather_rows(self.model.embed_tokens.weight, None, tokens.contiguous(), self.model.embed_tokens.weight.shape[1])
+        return ops.linear_fwd(self.model.forward_decode(emb, cache), self.head())
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, images=None, max_new_tokens=16, eos_token_id=None,
+                 pad_token_id=None, do_sample=False, **kwargs):
+        """Greedy generation with a KV cache (the reference's eval path calls HF `generate` on the Eval model,
+        llava_qwen2_moe.py:629-681).  Right-padded prompts: every sample continues from its own length.  Returns the
+        NEW tokens [B, <= max_new_tokens] (int64; positions after a sample's EOS hold pad_token_id)."""
+        if do_sample:
+            raise NotImplementedError("sampling is not on this path: greedy decoding only")
+        was_training = self.training
+        self.eval()
+        cache, logits = self._prefill(input_ids, attention_mask, images, max_new_tokens)
+        B = logits.shape[0]
+        pad = eos_token_id if pad_token_id is None else pad_token_id
+        done = torch.zeros(B, dtype=torch.bool, device=logits.device)
+        out = []
+        for step in range(max_new_tokens):
+            nxt = K.row_argmax(logits)
+            tok = nxt.long()
+            if eos_token_id is not None:
+                tok = torch.where(done, torch.full_like(tok, pad if pad is not None else 0), tok)
+                done = done | (tok == eos_token_id)
+            out.append(tok)
+            if step + 1 == max_new_tokens or (eos_token_id is not None and bool(done.all())):
+                break
+            logits = self._decode_step(nxt, cache)
+        self.train(was_training)
+        return torch.stack(out, 1)
+
+    # ---- checkpoints in the reference's layout -----------------------------------------------------------------------
+    def save_pretrained(self, save_directory, max_shard_bytes=5 << 30):
+        """config.json + HF-layout safetensors shards (+ mm_projector.bin), loadable by `from_pretrained`."""
+        import json
+        import os
+        from ...checkpoint import save_checkpoint
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {}
+        for k, v in vars(self.config).items():
+            if k == "mm_image_tower" and not isinstance(v, (str, type(None))):
+                cfg[k] = {"__clip_vision_config__": {a: b for a, b in vars(v).items()}}
+            elif isinstance(v, (str, int, float, bool, type(None), list, dict)):
+                cfg[k] = v
+        cfg["model_type"] = getattr(self.config, "model_type", None)
+        cfg["architectures"] = [type(self).__name__]
+        json.dump(cfg, open(os.path.join(save_directory, "config.json"), "w"), indent=1)
+        return save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, attn_implementation=None, torch_dtype=None,
+                        device="cuda", strict=True, config=None, cache_dir=None, **kwargs):
+        """`X.from_pretrained(path, attn_implementation=...)` of the reference's entry scripts (train/align_train.py:133-139):
+        read config.json, build the architecture, load the weights by name.  attn_implementation is recorded only (there is
+        one attention implementation here: the HIP flash kernels); torch_dtype must be bf16 (the compute dtype)."""
+        import json
+        import os
+        from ...checkpoint import load_checkpoint
+        from ..multimodal_encoder.clip_encoder import CLIPVisionConfig
+        if torch_dtype not in (None, torch.bfloat16):
+            raise ValueError("this path computes in bf16: torch_dtype must be torch.bfloat16 (or None)")
+        path = pretrained_model_name_or_path
+        if config is None:
+            raw = json.load(open(os.path.join(path, "config.json")))
+            raw.update(kwargs)
+            moe = raw.pop("moe", None)
+            for drop in ("architectures", "model_type", "transformers_version", "torch_dtype", "lora"):
+                raw.pop(drop, None)
+            tower = raw.get("mm_image_tower")
+            if isinstance(tower, dict) and "__clip_vision_config__" in tower:
+                raw["mm_image_tower"] = CLIPVisionConfig(**tower["__clip_vision_config__"])
+            config = cls.config_class(**raw)
+            if moe is not None:
+                config.moe = moe
+        config._attn_implementation = attn_implementation
+        model = cls(config, device=device)
+        load_checkpoint(model, path, strict=strict)
+        return model
+
     def lm_loss_from_hidden(self, hidden, info):
         """Shifted CrossEntropyLoss() of the reference forward (mean over non-ignored), loss rows only."""
         plan = build_loss_plan(info.labels_np, info.lens_np, kd_rows=False, ce_rows=True, device=hidden.device)
@@ -147,6 +282,8 @@ class LlavaQwen2ForCausalLM(_CausalLMBase):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 images=None, return_dict=None):
+        if use_cache or past_key_values is not None:
+            return self._cached_forward(input_ids, attention_mask, images, past_key_values, CausalLMOutputWithPast)
         hidden, _, info = self.forward_hidden(input_ids, attention_mask, labels, images, inputs_embeds)
         logits = self.full_logits(hidden, info.B, info.S)
         loss = self.lm_loss_from_hidden(hidden, info) if info.labels is not None else None

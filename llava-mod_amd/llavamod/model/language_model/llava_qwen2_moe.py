@@ -56,6 +56,8 @@ class LLaVAMoDQwen2ForCausalLM(_CausalLMBase):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 images=None, return_dict=None):
+        if use_cache or past_key_values is not None:
+            return self._cached_forward(input_ids, attention_mask, images, past_key_values, MoECausalLMOutputWithPast)
         hidden, moe_list, info = self.forward_hidden(input_ids, attention_mask, labels, images, inputs_embeds)
         logits = self.full_logits(hidden, info.B, info.S)
         loss = self.lm_loss_from_hidden(hidden, info) if info.labels is not None else None
@@ -147,6 +149,15 @@ class LLaVAMoDQwen2ForCausalLMFineTune(LLaVAMoDQwen2ForCausalLM):
 
 
 class EvalLLaVAMoDQwen2ForCausalLM(LLaVAMoDQwen2ForCausalLMFineTune):
+    """Inference variant (llava_qwen2_moe.py:629-681): MoE layers rebuilt from the saved config.moe like the FineTune class,
+    every parameter frozen, eval mode (the gate then uses eval_capacity_factor); `generate` / `prepare_inputs_for_generation`
+    come from the shared base (KV cache + single-query attention kernel)."""
+
+    def __init__(self, config, device="cuda"):
+        super().__init__(config, device)
+        self.requires_grad_(False)
+        self.eval()
+
     def initialize_moe_modules(self, model_args):
         raise NotImplementedError("Eval model: no training-time initialisation")
 

@@ -56,6 +56,21 @@ class _Linear(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_f, device=device, dtype=dtype)) if bias else None
 
 
+class KVCache:
+    """Per-layer key/value cache for generation (the reference relies on HF's DynamicCache through
+    prepare_inputs_for_generation, llava_qwen2_moe.py:453-473).  k/v: [L][B, Smax, nkv*hd] bf16, post-RoPE keys;
+    lens [B] int32 = number of valid positions per sample (right-padded prompts keep their own length)."""
+
+    def __init__(self, n_layers, B, smax, width, device):
+        self.k = [torch.zeros((B, smax, width), device=device, dtype=BF16) for _ in range(n_layers)]
+        self.v = [torch.zeros((B, smax, width), device=device, dtype=BF16) for _ in range(n_layers)]
+        self.lens = torch.zeros(B, device=device, dtype=torch.int32)
+        self.smax = smax
+
+    def get_seq_length(self):
+        return int(self.lens.max())
+
+
 class Qwen2RMSNorm(nn.Module):
     def __init__(self, hidden_size, eps, device):
         super().__init__()
@@ -82,8 +97,21 @@ class Qwen2Attention(nn.Module):
     def forward(self, x, rt, rows=None, inv_rows=None):
         spec = SimpleNamespace(qkv=self._qkv.ensure(), o=self._o.ensure(), B=rt.B, S=rt.S, nh=self.nh, nkv=self.nkv,
                                hd=self.hd, cos=rt.cos, sin=rt.sin, pos=rt.pos, scale=1.0 / math.sqrt(self.hd),
-                               seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows)
+                               seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows,
+                               kv_out=(rt.cache.k[rt.layer], rt.cache.v[rt.layer]) if getattr(rt, "cache", None) is not None else None)
         return ops.AttnBlock.apply(x, spec, *self.trainable())
+
+    def forward_decode(self, x, rt):
+        """One new token per sample against the cache: x [B, H] -> [B, H] (no autograd)."""
+        nh, nkv, hd = self.nh, self.nkv, self.hd
+        qkv = ops.linear_fwd(x, self._qkv.ensure())
+        K.rope_(qkv, rt.cos, rt.sin, rt.pos, nh + nkv, hd)                       # position = current length of the sample
+        kc, vc = rt.cache.k[rt.layer], rt.cache.v[rt.layer]
+        bi = rt.batch_index
+        kc[bi, rt.pos_long] = qkv[:, nh * hd:(nh + nkv) * hd]                    # append (indexed copy, no arithmetic)
+        vc[bi, rt.pos_long] = qkv[:, (nh + nkv) * hd:]
+        o = K.attn_decode(qkv[:, :nh * hd], kc, vc, rt.lens_after, nh, nkv, hd, 1.0 / math.sqrt(hd))
+        return ops.linear_fwd(o, self._o.ensure())
 
 
 class Qwen2MLP(nn.Module):
@@ -128,6 +156,15 @@ class Qwen2DecoderLayer(nn.Module):
             m = m[0]
         return m, h2, moe_losses
 
+    def forward_decode(self, delta, res, rt):
+        n1, _, h = K.rmsnorm_fwd(delta, self.input_layernorm.weight, self.input_layernorm.variance_epsilon, res=res)
+        a = self.self_attn.forward_decode(n1, rt)
+        n2, _, h2 = K.rmsnorm_fwd(a, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon, res=h)
+        m = self.mlp(n2, rt)
+        if isinstance(m, tuple):
+            m = m[0]
+        return m, h2
+
     def forward_rows(self, delta, res, rt, rows, inv_rows):
         """Same layer, but everything after the attention core runs only on token rows `rows` (int32 [R]; inv_rows[t] =
         position of t in rows or -1): the LAST layer of a model whose consumer reads R << T rows (the loss rows).  The
@@ -169,15 +206,36 @@ class Qwen2Model(nn.Module):
         pos = torch.arange(S, device=device, dtype=torch.int32).repeat(B)          # position_ids = arange(S')
         return SimpleNamespace(B=B, S=S, cos=cos, sin=sin, pos=pos, seqlens=seqlens)
 
-    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None, inv_rows=None):
+    def forward_decode(self, inputs_embeds, cache):
+        """inputs_embeds [B, H]: the embeddings of ONE new token per sample; appends to `cache` and returns the
+        final-normed hidden states [B, H]."""
+        dev = inputs_embeds.device
+        B = inputs_embeds.shape[0]
+        cos, sin = rope_tables(self.config.head_dim, max(self.config.max_position_embeddings, cache.smax),
+                               self.config.rope_theta, dev)
+        pos = cache.lens.clone()                                                   # position_ids of the new tokens
+        rt = SimpleNamespace(B=B, S=1, cos=cos, sin=sin, pos=pos, seqlens=None, cache=cache, layer=0,
+                             pos_long=pos.long(), batch_index=torch.arange(B, device=dev), lens_after=pos + 1)
+        delta, res = inputs_embeds, None
+        with torch.no_grad():
+            for i, layer in enumerate(self.layers):
+                rt.layer = i
+                delta, res = layer.forward_decode(delta, res, rt)
+            y, _, _ = K.rmsnorm_fwd(delta, self.norm.weight, self.norm.variance_epsilon, res=res)
+        cache.lens += 1
+        return y
+
+    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None, inv_rows=None, cache=None):
         """inputs_embeds: [B*S, H].  Returns (final-normed hidden [B*S, H], list of l_aux).  out_rows (int32 [R]) with
         inv_rows (int32 [B*S]): return just those rows, [R, H] — a dense last layer then skips o_proj / MLP / norm work
         (forward and backward) on every other row."""
         rt = self.runtime(B, S, seqlens, inputs_embeds.device)
+        rt.cache = cache                       # generation prefill: every layer stores its post-RoPE K and V
         delta, res = inputs_embeds, None
         all_moe = []
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
+            rt.layer = i
             if i == last and out_rows is not None and type(layer.mlp) is Qwen2MLP:
                 delta, res = layer.forward_rows(delta, res, rt, out_rows, inv_rows)
                 out_rows = None

@@ -224,6 +224,10 @@ class AttnBlock(torch.autograd.Function):
         qkv = linear_fwd(x, spec.qkv)
         K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        kv_out = getattr(spec, "kv_out", None)
+        if kv_out is not None:                  # generation prefill: keep the post-RoPE keys and the values
+            kv_out[0][:, :S].copy_(k.view(B, S, nkv * hd))
+            kv_out[1][:, :S].copy_(v.view(B, S, nkv * hd))
         rows = getattr(spec, "rows", None)      # last layer of a model whose consumer reads only these token rows
         need = _need(ctx)
         if need:
