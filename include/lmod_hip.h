@@ -137,12 +137,14 @@ int lmod_cast_f32_bf16(const void* src, void* dst, long long n, int to_bf16, hip
 /* ---- attention -------------------------------------------------------------------------------
  * softmax(Q K^T * scale + mask) V with causal and right-padding masks, GQA (nh % nkv == 0).
  * Replaces F.scaled_dot_product_attention / flash_attn (qwen2/modeling_qwen2.py:700-708,535-581)
- * and CLIP encoder attention.  hd in {64, 128}.  lse: [B, nh, S] fp32 (may be NULL in fwd). */
-int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens, int B, int S,
-                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
-                  hipStream_t stream);
+ * and CLIP encoder attention.  hd in {64, 128}.  lse: [B, nh, S] fp32 (may be NULL in fwd).
+ * cu_seqlens (nullable, hd 128 only): UNPADDED layout — the samples' tokens are packed back to back, sample b occupies rows
+ * cu_seqlens[b] .. cu_seqlens[b+1]-1 and S is the longest sample (lse / delta keep the [B, nh, S] layout). */
+int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens,
+                  const int* cu_seqlens, int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
+                  int causal, hipStream_t stream);
 int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, int B, int S, int nh, int nkv,
+                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S, int nh, int nkv,
                   int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
                   int causal, hipStream_t stream);
 
@@ -151,6 +153,28 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
  * at column hk*hd, keys 0 .. lens[b]-1 valid, the new token's key/value already appended), out [B, ldo]. */
 int lmod_attn_decode(const void* q, const void* kcache, const void* vcache, const int* lens, void* out, int B, int nh,
                      int nkv, int hd, int smax, int ldq, int ld_cache, int ldo, float scale, hipStream_t stream);
+
+/* ---- multimodal splice / loss-row plans built on the device ----------------------------------------
+ * prepare_inputs_labels_for_multimodal (llava_arch.py:155-334) as index maps, from int tensors already on the device.
+ * lmod_splice_count: per sample the spliced length (pads stripped by attention_mask, every -200 token replaced by
+ *   n_patches rows, cut at max_length if > 0) and the number of image slots it consumes (max(#-200, 1), :238-246).
+ * lmod_splice_fill (S = max spliced length, read back by the host): idx[B*S] (>= 0: embedding row; <= -2: projector
+ *   row -(idx+2); -1: right padding), new_labels[B*S] (-100 over image rows and padding), new_mask[B*S] (nullable),
+ *   inv_idx[n_images_total * n_patches] (position of every projector row, -1 if cut; caller pre-fills with -1).
+ * lmod_lossplan_*: rows of the [B*S] hidden states that carry loss (KD row t: labels[t] != -100, or every row when
+ *   all_tokens — align_trainer.py:516-522; CE row t: labels[t+1] != -100 — llava_qwen2_moe.py:413-421), compacted in
+ *   sample-major order: row_idx[R], inv_row_idx[B*S], kd_w/ce_w[R], ce_label[R] (-1 where no CE), seg_off[B+1], seg_id[R];
+ *   R = sum(counts) is read back by the host between the two calls.  attention_mask: bytes (bool). */
+int lmod_splice_count(const long long* input_ids, const unsigned char* attention_mask, int B, int T, int n_patches,
+                      int max_length, int* lens, int* n_images, hipStream_t stream);
+int lmod_splice_fill(const long long* input_ids, const unsigned char* attention_mask, const long long* labels, int B, int T,
+                     int n_patches, int S, const int* lens, const int* n_images, int* idx, long long* new_labels,
+                     unsigned char* new_mask, int* inv_idx, hipStream_t stream);
+int lmod_lossplan_count(const long long* labels, int B, int S, int kd_rows, int ce_rows, int all_tokens, int* counts,
+                        hipStream_t stream);
+int lmod_lossplan_fill(const long long* labels, int B, int S, int kd_rows, int ce_rows, int all_tokens, const int* counts,
+                       int* row_idx, int* inv_row_idx, float* kd_w, float* ce_w, int* ce_label, int* seg_off, int* seg_id,
+                       hipStream_t stream);
 
 /* Greedy decoding: out[r] = argmax_v logits[r, v] over bf16 rows (first maximum wins). */
 int lmod_row_argmax_bf16(const void* logits, long long ld, int V, int* out, int R, hipStream_t stream);

@@ -318,19 +318,28 @@ __global__ __launch_bounds__(NTHR, 2) void attn_fwd_kernel(AttnP p) {
 // 16 lanes per (token, head): 4 pairs per wave (one pair per wave left 48 of 64 lanes idle at hd 128)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                         float* __restrict__ delta, int B, int S, int nh, int HD,
-                                                        int lddo, int ldo) {
+                                                        int lddo, int ldo, const int* __restrict__ cu) {
   const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
   const long long id = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;   // (b, s, h)
   const long long total = (long long)B * S * nh;
   float a = 0.f;
   long long tok = 0; int h = 0;
   const bool live = id < total;
+  bool valid = live;
   if (live) {
     h = (int)(id % nh);
-    tok = id / nh;
+    tok = id / nh;                           // (b, s) with s < S; varlen: packed row cu[b] + s, skipped past the sample's end
+  }
+  long long row = tok;
+  if (live && cu) {
+    const int bb = (int)(tok / S), ss = (int)(tok % S);
+    valid = ss < cu[bb + 1] - cu[bb];
+    row = (long long)cu[bb] + ss;
+  }
+  if (valid) {
     for (int cidx = c; cidx < (HD >> 3); cidx += 16) {
-      const u32x4 x = *(const u32x4*)(dO + tok * lddo + h * HD + cidx * 8);
-      const u32x4 y = *(const u32x4*)(O + tok * ldo + h * HD + cidx * 8);
+      const u32x4 x = *(const u32x4*)(dO + row * lddo + h * HD + cidx * 8);
+      const u32x4 y = *(const u32x4*)(O + row * ldo + h * HD + cidx * 8);
 #pragma unroll
       for (int k = 0; k < 4; ++k) a += bflo(x[k]) * bflo(y[k]) + bfhi(x[k]) * bfhi(y[k]);
     }
@@ -357,10 +366,11 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnP& p, char* smem, in
   const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hk = h / p.group;
-  const int S = p.S;
+  const int S = p.cu ? (p.cu[b + 1] - p.cu[b]) : p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
   const int q0 = qb * QB, qw0 = q0 + wave * 32;
-  const long long tok0 = (long long)b * S;
+  if (q0 >= S) return;
+  const long long tok0 = p.cu ? (long long)p.cu[b] : (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
 
   bf16x8 qf[2][KS];
@@ -373,7 +383,7 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnP& p, char* smem, in
       if (q < S) qf[qt][ks] = *(const bf16x8*)(p.Q + (tok0 + q) * p.ldq + h * HD + ks * 32 + g * 8);
       else qf[qt][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
-    const long long si = ((long long)b * p.nh + h) * S + min(q, S - 1);
+    const long long si = ((long long)b * p.nh + h) * p.S + min(q, S - 1);
     lse2[qt] = p.LSE[si] * 1.4426950408889634f;
     dl[qt] = p.Delta[si];
   }
@@ -501,11 +511,12 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnP& p, char* smem, i
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int S = p.S;
+  const int S = p.cu ? (p.cu[b + 1] - p.cu[b]) : p.S;
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
   const int k0 = kb * KBLK, kw0 = k0 + wave * 16;
+  if (k0 >= S) return;
   const int key = kw0 + li;
-  const long long tok0 = (long long)b * S;
+  const long long tok0 = p.cu ? (long long)p.cu[b] : (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
 
   bf16x8 kf[KS], vf[KS];
@@ -535,7 +546,7 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnP& p, char* smem, i
     const int h = hk * p.group + hh, q0 = j * 64;
     qst.load(p.Q + (tok0 + q0) * p.ldq + h * HD, p.ldq, S - q0, tid);
     ost.load(p.dO + (tok0 + q0) * p.lddo + h * HD, p.lddo, S - q0, tid);
-    const long long si = ((long long)b * p.nh + h) * S;
+    const long long si = ((long long)b * p.nh + h) * p.S;
     if (tid < 64) ld_reg = (q0 + tid < S) ? p.LSE[si + q0 + tid] * 1.4426950408889634f : 0.f;
     else if (tid < 128) ld_reg = (q0 + tid - 64 < S) ? p.Delta[si + q0 + tid - 64] : 0.f;
   };
@@ -639,20 +650,21 @@ extern "C" {
 // Q [B*S, ldq] (head h at column h*hd), K/V [B*S, ldk/ldv] (kv head at column hk*hd); O [B*S, ldo];
 // lse [B, nh, S] fp32 (natural log of the scaled-score partition function; may be NULL).
 // seqlens [B] i32 or NULL: keys >= seqlens[b] are masked.
-int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens, int B, int S,
-                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
-                  hipStream_t stream) {
+int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens,
+                  const int* cu_seqlens, int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
+                  int causal, hipStream_t stream) {
   if (!Q || !K || !V || !O) return LMOD_EINVAL;
   int rc = check_common(B, S, nh, nkv, hd, ldq, ldk, ldv);
   if (rc) return rc;
   if ((ldo & 7) || ldo < nh * hd) return LMOD_EINVAL;
   AttnP p = {};
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = lse;
-  p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
+  p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
+  if (cu_seqlens && (hd != 128 || seqlens)) return LMOD_EUNSUPPORTED;      // packed (varlen) layout: the hd-128 kernels only
   static int fwd_ver = -1;         // LMOD_ATTN_FWD=1: the round-1 16x16x32 kernel for hd 128 as well (A/B runs)
   if (fwd_ver < 0) { const char* e = getenv("LMOD_ATTN_FWD"); fwd_ver = e ? atoi(e) : 2; }
-  if (hd == 128 && fwd_ver != 1) { lmod_launch_attn_fwd2(p, causal, stream); return lmod_launch_status(); }
+  if (hd == 128 && (fwd_ver != 1 || cu_seqlens)) { lmod_launch_attn_fwd2(p, causal, stream); return lmod_launch_status(); }
   constexpr int QB = NWAVE * 32;
   const int nqb = (S + QB - 1) / QB;
   const dim3 grid(causal ? (nqb + 1) / 2 : nqb, nh, B);
@@ -666,9 +678,9 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
 
 // delta_ws: [B, nh, S] fp32 workspace.  dQ/dK/dV use the same layouts as Q/K/V (own leading dims).
 int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, int B, int S, int nh, int nkv,
-                  int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
-                  int causal, hipStream_t stream) {
+                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                  float scale, int causal, hipStream_t stream) {
   if (!Q || !K || !V || !O || !dO || !lse || !delta_ws || !dQ || !dK || !dV) return LMOD_EINVAL;
   int rc = check_common(B, S, nh, nkv, hd, ldq, ldk, ldv);
   if (rc) return rc;
@@ -678,12 +690,13 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   AttnP p = {};
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = (float*)lse;
   p.dO = (const bf16_t*)dO; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
-  p.seqlens = seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
+  p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale;
+  if (cu_seqlens && (hd != 128 || seqlens)) return LMOD_EUNSUPPORTED;
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
-                     (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo);
+                     (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo, cu_seqlens);
   constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;
   const int nqb = (S + QB - 1) / QB, nkb = (S + KBLK - 1) / KBLK;
   const dim3 gq(causal ? (nqb + 1) / 2 : nqb, nh, B), gk(causal ? (nkb + 1) / 2 : nkb, nkv, B);

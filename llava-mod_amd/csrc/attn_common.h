@@ -17,6 +17,7 @@ struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
   const bf16_t* dO; const float* Delta; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
   const int* seqlens;
+  const int* cu;                 // varlen: token offsets [B+1] of the PACKED samples (S = longest sample), or NULL (b*S)
   int B, S, nh, group;           // group = nh / nkv
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   float scale;

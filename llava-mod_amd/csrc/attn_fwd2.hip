@@ -258,11 +258,12 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hk = h / p.group;
-  const int S = p.S;
+  const int S = p.cu ? (p.cu[b + 1] - p.cu[b]) : p.S;             // varlen: this sample's own length, tokens packed
   const int len = p.seqlens ? min(p.seqlens[b], S) : S;
   const int q0 = qb * QB, qw0 = q0 + wave * 32;
+  if (q0 >= S) return;                                           // (varlen) query block past the end of a short sample
   const int q = qw0 + l31;
-  const long long tok0 = (long long)b * S;
+  const long long tok0 = p.cu ? (long long)p.cu[b] : (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
 
   const int kv_end = CAUSAL ? min(q0 + QB, len) : len;
@@ -525,7 +526,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     store_strip(std::integral_constant<int, 0>{}); store_strip(std::integral_constant<int, 1>{});
     store_strip(std::integral_constant<int, 2>{}); store_strip(std::integral_constant<int, 3>{});
     if (hi == 0 && p.LSE)
-      p.LSE[((long long)b * p.nh + h) * S + q] =
+      p.LSE[((long long)b * p.nh + h) * p.S + q] =
           (lt > 0.f) ? mrun * p.scale + __builtin_amdgcn_logf(lt) * 0.6931471805599453f : -INFINITY;
   }
 }

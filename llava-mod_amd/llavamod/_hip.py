@@ -36,8 +36,12 @@ SIGNATURES = {
     "lmod_sumsq_f32": "pq" + "pp" + "i" + "p",
     "lmod_clip_coef": "pff" + "pp" + "p",
     "lmod_cast_f32_bf16": "pp" + "qi" + "p",
-    "lmod_attn_fwd": "pppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
-    "lmod_attn_bwd": "ppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
+    "lmod_attn_fwd": "ppppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
+    "lmod_attn_bwd": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
+    "lmod_splice_count": "pp" + "iiii" + "pp" + "p",
+    "lmod_splice_fill": "ppp" + "iiii" + "pp" + "pppp" + "p",
+    "lmod_lossplan_count": "p" + "iiiii" + "p" + "p",
+    "lmod_lossplan_fill": "p" + "iiiii" + "p" + "ppppppp" + "p",
     "lmod_row_argmax_bf16": "pqi" + "pi" + "p",
     "lmod_attn_decode": "ppppp" + "iiiiiiii" + "f" + "p",
     "lmod_moe_router_fwd": "ppp" + "iii" + "p",

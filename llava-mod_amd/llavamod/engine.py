@@ -449,7 +449,7 @@ def init_distributed():
         return 0, 0, 1
     rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and os.environ.get("LMOD_DIST_BACKEND", "nccl") != "gloo":   # gloo: CPU multi-process tests
         torch.cuda.set_device(local)
         # RCCL's communication streams at HIGH priority: the step's compute stream is a high-priority stream too (the
         # prefetched teacher pass runs below both), and a default-priority all-reduce would starve behind it

@@ -247,19 +247,20 @@ def cast_f32_bf16(src, dst):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, B, S, nh, nkv, hd, scale, causal, seqlens=None, want_lse=True):
-    """q/k/v: 2-D views [B*S, ld] whose column 0 is head 0 (views into a fused QKV buffer are fine)."""
-    o = torch.empty((B * S, nh * hd), device=q.device, dtype=BF16)
+def attn_fwd(q, k, v, B, S, nh, nkv, hd, scale, causal, seqlens=None, want_lse=True, cu=None):
+    """q/k/v: 2-D views [T, ld] whose column 0 is head 0 (views into a fused QKV buffer are fine).  Padded layout: T = B*S,
+    sample b at rows b*S.., keys >= seqlens[b] masked.  Packed (cu [B+1] int32, hd 128): T = cu[B], S = longest sample."""
+    o = torch.empty((q.shape[0], nh * hd), device=q.device, dtype=BF16)
     lse = torch.empty((B, nh, S), device=q.device, dtype=torch.float32) if want_lse else None
-    call("lmod_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(seqlens), B, S, nh, nkv, hd, q.stride(0),
+    call("lmod_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0),
          k.stride(0), v.stride(0), o.stride(0), float(scale), int(causal))
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None):
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None, cu=None):
     delta = torch.empty((B, nh, S), device=q.device, dtype=torch.float32)
     call("lmod_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-         ptr(seqlens), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+         ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
          dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
     return dq, dk, dv
 

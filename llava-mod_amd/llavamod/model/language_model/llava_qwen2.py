@@ -40,6 +40,8 @@ def build_loss_plan(labels_np, lens_np, kd_rows=True, ce_rows=True, distill_all_
                                                when distill_all_tokens, :516-520)
       CE row t  : labels[b,t+1] != -100        (shifted LM / DPO rows, llava_qwen2_moe.py:413-421, dpo_trainer.py:483-485)
     """
+    if torch.is_tensor(labels_np):
+        return build_loss_plan_device(labels_np, kd_rows, ce_rows, distill_all_tokens, align_vocab)
     B, S = labels_np.shape
     valid = labels_np != IGNORE_INDEX
     kd = (np.ones_like(valid) if distill_all_tokens else valid) if kd_rows else np.zeros_like(valid)
@@ -61,6 +63,36 @@ def build_loss_plan(labels_np, lens_np, kd_rows=True, ce_rows=True, distill_all_
                            seg_off=t(seg_off), seg_id=t(bi.astype(np.int32)), align_vocab=align_vocab, shape=(B, S),
                            labels_np=labels_np,
                            n_kd=int(kd.sum()), n_ce=int(ce.sum()))
+
+
+def build_loss_plan_device(labels, kd_rows=True, ce_rows=True, distill_all_tokens=False, align_vocab=None):
+    """`build_loss_plan` on the device (csrc/splice.hip) from the spliced labels [B, S'] (device int64): two launches and
+    one B-int read-back (R, the number of loss rows, sizes the outputs)."""
+    from ..._hip import call, ptr
+    dev = labels.device
+    B, S = labels.shape
+    lb = labels.to(torch.int64).contiguous()
+    counts = torch.empty(B, device=dev, dtype=torch.int32)
+    flags = (int(bool(kd_rows)), int(bool(ce_rows)), int(bool(distill_all_tokens)))
+    call("lmod_lossplan_count", ptr(lb), B, S, *flags, ptr(counts))
+    R = int(counts.sum().item())
+    i32 = dict(device=dev, dtype=torch.int32)
+    row_idx, inv = torch.empty(R, **i32), torch.empty(B * S, **i32)
+    kd_w, ce_w = torch.empty(R, device=dev), torch.empty(R, device=dev)
+    ce_label, seg_off, seg_id = torch.empty(R, **i32), torch.empty(B + 1, **i32), torch.empty(R, **i32)
+    call("lmod_lossplan_fill", ptr(lb), B, S, *flags, ptr(counts), ptr(row_idx), ptr(inv), ptr(kd_w), ptr(ce_w), ptr(ce_label),
+         ptr(seg_off), ptr(seg_id))
+    return SimpleNamespace(R=R, row_idx=row_idx, inv_row_idx=inv, kd_w=kd_w, ce_w=ce_w, ce_label=ce_label, seg_off=seg_off,
+                           seg_id=seg_id, align_vocab=align_vocab, shape=(B, S), labels_np=None, labels_dev=lb,
+                           n_kd=None, n_ce=None)
+
+
+def _inverse_map(packed):
+    """packed row -> padded position (int32 [T]), cached on the plan."""
+    if getattr(packed, "from_packed", None) is None:
+        keep = np.nonzero(packed.to_packed_np >= 0)[0].astype(np.int32)
+        packed.from_packed = torch.from_numpy(keep).to(packed.to_packed.device)
+    return packed.from_packed
 
 
 class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
@@ -97,6 +129,9 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             plan = None
         B, S, H = inputs_embeds.shape
         seqlens = None
+        packed = plan is not None and getattr(plan, "cu", None) is not None      # unpadded (varlen) execution
+        if packed:
+            B, S = plan.B, plan.S                              # embeds arrive as packed rows [1, T, H]
         if plan is not None:
             seqlens = plan.seqlens
         elif attention_mask is not None:
@@ -104,7 +139,10 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             if bool((lens != S).any()):
                 seqlens = lens.to(device=inputs_embeds.device, dtype=torch.int32).contiguous()
         if labels is not None:
-            labels_np = plan.labels_np if plan is not None else labels.detach().cpu().numpy()
+            if plan is not None:
+                labels_np = plan.labels_np if plan.labels_np is not None else labels      # device-built plan: stay on device
+            else:
+                labels_np = labels if labels.is_cuda else labels.detach().cpu().numpy()
         else:
             labels_np = None
         lens_np = plan.lens_np if plan is not None else None
@@ -113,10 +151,18 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         out_rows = inv_rows = None
         if plan_fn is not None and labels_np is not None:
             info.plan = plan_fn(info)
+            if packed:
+                from ..llava_arch import pack_loss_plan
+                info.plan = pack_loss_plan(info.plan, plan)
             info.plan.pregathered = True
             out_rows, inv_rows = info.plan.row_idx, info.plan.inv_row_idx
-        hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens, out_rows=out_rows,
-                                      inv_rows=inv_rows)
+        if packed:
+            info.packed = plan
+            hidden, moe_list = self.model(inputs_embeds.reshape(-1, H), B, S, None, out_rows=out_rows, inv_rows=inv_rows,
+                                          cu=plan.cu, pos=plan.pos)
+        else:
+            hidden, moe_list = self.model(inputs_embeds.reshape(B * S, H), B, S, seqlens, out_rows=out_rows,
+                                          inv_rows=inv_rows)
         return hidden, moe_list, info
 
     # ---- generation (KV cache) -------------------------------------------------------------------------------------
@@ -257,13 +303,18 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
     def lm_loss_from_hidden(self, hidden, info):
         """Shifted CrossEntropyLoss() of the reference forward (mean over non-ignored), loss rows only."""
         plan = build_loss_plan(info.labels_np, info.lens_np, kd_rows=False, ce_rows=True, device=hidden.device)
+        if getattr(info, "packed", None) is not None:
+            from ..llava_arch import pack_loss_plan
+            plan = pack_loss_plan(plan, info.packed)
         _, _, ce_sum, ce_cnt = ops.DistillHead.apply(hidden, self.head(), plan, None, *self._head_trainable())
         return ce_sum.sum() / ce_cnt.sum()
 
     def _head_trainable(self):
         return [self.lm_head.weight] if self.lm_head.weight.requires_grad else []
 
-    def full_logits(self, hidden, B, S):
+    def full_logits(self, hidden, B, S, packed=None):
+        if packed is not None:                 # unpadded execution: back to the reference's padded [B, S', V] (zero rows on pads)
+            hidden = ops.RowGather.apply(hidden, packed.to_packed, _inverse_map(packed))
         lg = ops.Linear.apply(hidden, self.head(), *self._head_trainable())
         return lg.view(B, S, -1).float()                        # `logits = logits.float()` (modeling_qwen2.py:1164)
 
@@ -285,7 +336,7 @@ class LlavaQwen2ForCausalLM(_CausalLMBase):
         if use_cache or past_key_values is not None:
             return self._cached_forward(input_ids, attention_mask, images, past_key_values, CausalLMOutputWithPast)
         hidden, _, info = self.forward_hidden(input_ids, attention_mask, labels, images, inputs_embeds)
-        logits = self.full_logits(hidden, info.B, info.S)
+        logits = self.full_logits(hidden, info.B, info.S, getattr(info, "packed", None))
         loss = self.lm_loss_from_hidden(hidden, info) if info.labels is not None else None
         return CausalLMOutputWithPast(loss=loss, logits=logits, labels=info.labels)
 

@@ -59,7 +59,7 @@ class LLaVAMoDQwen2ForCausalLM(_CausalLMBase):
         if use_cache or past_key_values is not None:
             return self._cached_forward(input_ids, attention_mask, images, past_key_values, MoECausalLMOutputWithPast)
         hidden, moe_list, info = self.forward_hidden(input_ids, attention_mask, labels, images, inputs_embeds)
-        logits = self.full_logits(hidden, info.B, info.S)
+        logits = self.full_logits(hidden, info.B, info.S, getattr(info, "packed", None))
         loss = self.lm_loss_from_hidden(hidden, info) if info.labels is not None else None
         moe_loss = self.moe_loss_from_list(moe_list)
         if moe_loss is not None and loss is not None:

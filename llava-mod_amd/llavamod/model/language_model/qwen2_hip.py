@@ -97,7 +97,7 @@ class Qwen2Attention(nn.Module):
     def forward(self, x, rt, rows=None, inv_rows=None):
         spec = SimpleNamespace(qkv=self._qkv.ensure(), o=self._o.ensure(), B=rt.B, S=rt.S, nh=self.nh, nkv=self.nkv,
                                hd=self.hd, cos=rt.cos, sin=rt.sin, pos=rt.pos, scale=1.0 / math.sqrt(self.hd),
-                               seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows,
+                               seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows, cu=getattr(rt, "cu", None),
                                kv_out=(rt.cache.k[rt.layer], rt.cache.v[rt.layer]) if getattr(rt, "cache", None) is not None else None)
         return ops.AttnBlock.apply(x, spec, *self.trainable())
 
@@ -200,11 +200,12 @@ class Qwen2Model(nn.Module):
         self.layers = nn.ModuleList([Qwen2DecoderLayer(cfg, device) for _ in range(cfg.num_hidden_layers)])
         self.norm = Qwen2RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
 
-    def runtime(self, B, S, seqlens, device):
+    def runtime(self, B, S, seqlens, device, cu=None, pos=None):
         cos, sin = rope_tables(self.config.head_dim, max(self.config.max_position_embeddings, S),
                                self.config.rope_theta, device)
-        pos = torch.arange(S, device=device, dtype=torch.int32).repeat(B)          # position_ids = arange(S')
-        return SimpleNamespace(B=B, S=S, cos=cos, sin=sin, pos=pos, seqlens=seqlens)
+        if pos is None:
+            pos = torch.arange(S, device=device, dtype=torch.int32).repeat(B)      # position_ids = arange(S')
+        return SimpleNamespace(B=B, S=S, cos=cos, sin=sin, pos=pos, seqlens=seqlens, cu=cu)
 
     def forward_decode(self, inputs_embeds, cache):
         """inputs_embeds [B, H]: the embeddings of ONE new token per sample; appends to `cache` and returns the
@@ -225,11 +226,11 @@ class Qwen2Model(nn.Module):
         cache.lens += 1
         return y
 
-    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None, inv_rows=None, cache=None):
+    def forward(self, inputs_embeds, B, S, seqlens=None, out_rows=None, inv_rows=None, cache=None, cu=None, pos=None):
         """inputs_embeds: [B*S, H].  Returns (final-normed hidden [B*S, H], list of l_aux).  out_rows (int32 [R]) with
         inv_rows (int32 [B*S]): return just those rows, [R, H] — a dense last layer then skips o_proj / MLP / norm work
         (forward and backward) on every other row."""
-        rt = self.runtime(B, S, seqlens, inputs_embeds.device)
+        rt = self.runtime(B, S, seqlens, inputs_embeds.device, cu=cu, pos=pos)   # cu/pos: packed rows (unpadded execution)
         rt.cache = cache                       # generation prefill: every layer stores its post-RoPE K and V
         delta, res = inputs_embeds, None
         all_moe = []

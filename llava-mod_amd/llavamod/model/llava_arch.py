@@ -117,6 +117,76 @@ def build_splice_plan(input_ids, attention_mask, labels, n_patches, max_length=N
         seqlens=torch.from_numpy(lens).to(device) if ragged else None)
 
 
+def pack_splice_plan(plan):
+    """Padded plan -> UNPADDED (varlen) plan: the samples' valid rows packed back to back (cu_seqlens), no padding rows in
+    any GEMM / row kernel / MoE gate.  Adds: cu (device int32 [B+1]), T (packed rows), pos (device int32 [T], position id of
+    every packed row), to_packed (device int32 [B*S], packed row of a padded position or -1); idx / inv_idx are rewritten
+    in packed coordinates.  Host-built plans are packed with numpy, device-built ones with a few int-tensor ops."""
+    B, S = plan.B, plan.S
+    lens = plan.lens_np.astype(np.int64)
+    cu_np = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu_np[1:])
+    T = int(cu_np[-1])
+    dev = plan.idx.device
+    keep_np = np.concatenate([b * S + np.arange(lens[b], dtype=np.int64) for b in range(B)]) if B else np.zeros(0, np.int64)
+    to_packed_np = np.full(B * S, -1, dtype=np.int32)
+    to_packed_np[keep_np] = np.arange(T, dtype=np.int32)
+    pos_np = (keep_np % S).astype(np.int32)
+    keep = torch.from_numpy(keep_np).to(dev)
+    to_packed = torch.from_numpy(to_packed_np).to(dev)
+    out = SimpleNamespace(**vars(plan))
+    out.idx = plan.idx[keep].contiguous()
+    inv = plan.inv_idx.long()
+    out.inv_idx = torch.where(inv >= 0, to_packed[inv.clamp_min(0)], torch.full_like(plan.inv_idx, -1)).contiguous()
+    out.cu = torch.from_numpy(cu_np).to(dev)
+    out.T, out.pos, out.to_packed, out.to_packed_np = T, torch.from_numpy(pos_np).to(dev), to_packed, to_packed_np
+    out.seqlens = None                                         # no key mask: a packed sample has no padding keys
+    return out
+
+
+def pack_loss_plan(lp, splice):
+    """Loss-row plan in padded coordinates -> packed coordinates (loss rows are never padding rows unless every token is
+    distilled, which the unpadded mode does not support: pads do not exist there)."""
+    if getattr(lp, "is_packed", False):                       # e.g. the teacher's plan reused for the student
+        return lp
+    to_packed = splice.to_packed
+    rows = to_packed[lp.row_idx.long()]
+    out = SimpleNamespace(**vars(lp))
+    out.is_packed = True
+    out.row_idx = rows.contiguous()
+    inv = torch.full((splice.T,), -1, device=rows.device, dtype=torch.int32)
+    inv[rows.long()] = torch.arange(rows.numel(), device=rows.device, dtype=torch.int32)
+    out.inv_row_idx = inv
+    return out
+
+
+def build_splice_plan_device(input_ids, attention_mask, labels, n_patches, max_length=None):
+    """The same plan as `build_splice_plan`, built ON THE DEVICE from device-resident [B, T] int64 ids / bool mask / int64
+    labels (csrc/splice.hip): two launches and one B-int read-back (the batch's spliced length S' sizes the outputs, exactly
+    as the reference's pad-to-max does).  labels_np is None: the loss plan is then built on the device too."""
+    from .._hip import call, ptr
+    dev = input_ids.device
+    B, T = input_ids.shape
+    ids = input_ids.to(torch.int64).contiguous()
+    am = attention_mask.to(torch.bool).contiguous().view(torch.uint8) if attention_mask is not None else None
+    lb = labels.to(torch.int64).contiguous() if labels is not None else None
+    cnt = torch.empty((2, B), device=dev, dtype=torch.int32)
+    call("lmod_splice_count", ptr(ids), ptr(am), B, T, n_patches, int(max_length or 0), ptr(cnt[0]), ptr(cnt[1]))
+    host = cnt.cpu().numpy()                                   # the one host sync of the splice: B lengths + B image counts
+    lens_np, S, n_img = host[0].astype(np.int32), int(host[0].max()), int(host[1].sum())
+    idx = torch.empty(B * S, device=dev, dtype=torch.int32)
+    new_lab = torch.empty((B, S), device=dev, dtype=torch.int64)
+    new_am = torch.empty((B, S), device=dev, dtype=torch.uint8) if attention_mask is not None else None
+    inv = torch.full((n_img * n_patches,), -1, device=dev, dtype=torch.int32)
+    call("lmod_splice_fill", ptr(ids), ptr(am), ptr(lb), B, T, n_patches, S, ptr(cnt[0]), ptr(cnt[1]), ptr(idx), ptr(new_lab),
+         ptr(new_am), ptr(inv))
+    ragged = bool((lens_np != S).any())
+    return SimpleNamespace(B=B, S=S, n_images=n_img, idx=idx, inv_idx=inv,
+                           labels=new_lab if labels is not None else None, labels_np=None, lens_np=lens_np,
+                           attention_mask=new_am.view(torch.bool) if new_am is not None else None,
+                           seqlens=cnt[0].clone() if ragged else None)
+
+
 class LlavaMetaForCausalLM:
     """Mixin for the *ForCausalLM classes (llava_arch.py:131-334)."""
 
@@ -150,12 +220,22 @@ class LlavaMetaForCausalLM:
         if imgs.dim() != 4:
             raise NotImplementedError("video inputs are not on the distillation path")
         P = tower.num_patches
-        plan = build_splice_plan(input_ids, attention_mask, labels, P,
-                                 getattr(self.config, "tokenizer_model_max_length", None), dev)
+        max_len = getattr(self.config, "tokenizer_model_max_length", None)
+        if input_ids.is_cuda:                                 # device-resident batch: index build on the device
+            plan = build_splice_plan_device(input_ids, attention_mask, labels, P, max_len)
+        else:
+            plan = build_splice_plan(input_ids, attention_mask, labels, P, max_len, dev)
         if plan.n_images != imgs.shape[0]:
             raise ValueError(f"batch consumes {plan.n_images} images but {imgs.shape[0]} were given")
+        if getattr(self, "unpad", False) and plan.seqlens is not None:
+            # UNPADDED (varlen) execution of a ragged batch: the decoder sees only the sum(len) real rows.  Opt-in, because
+            # the reference routes its padding rows through the MoE gate too (they take capacity slots and enter l_aux);
+            # here they do not exist.  Labels / mask keep the reference's padded [B, S'] shape.
+            plan = pack_splice_plan(plan)
         feats = self.encode_images(imgs)                      # [n_img*P, H]
         emb = ops.SpliceEmbed.apply(feats, model.embed_tokens.weight, plan.idx, plan.inv_idx)
         self._plan = plan
         H = emb.shape[1]
+        if getattr(plan, "cu", None) is not None:             # packed rows [T, H] (a 3-D view keeps the 6-tuple contract)
+            return None, None, plan.attention_mask, past_key_values, emb.view(1, plan.T, H), plan.labels
         return None, None, plan.attention_mask, past_key_values, emb.view(plan.B, plan.S, H), plan.labels

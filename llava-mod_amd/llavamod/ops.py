@@ -234,7 +234,8 @@ class AttnBlock(torch.autograd.Function):
             for fw in (spec.qkv, spec.o):
                 if fw.requires_grad:
                     fw.note_use()
-        o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need)
+        o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need,
+                            cu=getattr(spec, "cu", None))
         o_in = K.gather_rows(o, None, rows, o.shape[1]) if rows is not None else o    # o_proj on [R, nh*hd] only
         out = linear_fwd(o_in, spec.o)
         ctx.spec = spec
@@ -256,7 +257,8 @@ class AttnBlock(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
-                   dqkv[:, (nh + nkv) * hd:], sp.B, sp.S, nh, nkv, hd, sp.scale, True, sp.seqlens)
+                   dqkv[:, (nh + nkv) * hd:], sp.B, sp.S, nh, nkv, hd, sp.scale, True, sp.seqlens,
+                   cu=getattr(sp, "cu", None))
         K.rope_(dqkv, sp.cos, sp.sin, sp.pos, nh + nkv, hd, backward=True)
         dx = linear_dgrad(dqkv, sp.qkv)
         if sp.qkv.requires_grad:

@@ -111,7 +111,12 @@ class AlignTrainer:
         # shape mismatch at this point, align_trainer.py:470-471).
         def student_plan(info):
             tp = teacher_plan
-            if tp.shape != (info.B, info.S) or not (tp.labels_np == info.labels_np).all():
+            same = tp.shape == (info.B, info.S)
+            if same and tp.labels_np is not None and not torch.is_tensor(info.labels_np):
+                same = bool((tp.labels_np == info.labels_np).all())
+            elif same and torch.is_tensor(info.labels_np):          # device-built plans: compare on the device
+                same = bool(torch.equal(getattr(tp, "labels_dev", info.labels_np), info.labels_np))
+            if not same:
                 raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape: the student's and "
                                  f"the teacher's spliced sequences differ ({(info.B, info.S)} vs {tp.shape})")
             return copy.copy(tp)

@@ -25,7 +25,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")      # CPU test even on a box that has a GPU
     from llavamod.engine import DataParallel, GradBuffer, init_distributed
     from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2DecoderLayer
     from llavamod.model.moe_layer import MoE
@@ -136,7 +136,7 @@ def _cpu_kernels():
 
 def _zero2_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")      # CPU test even on a box that has a GPU
     from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
     from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2DecoderLayer, init_normal_
     from llavamod.model.moe_layer import MoE

@@ -658,7 +658,7 @@ def test_abi_error_codes_and_empty_inputs():
     assert g(64, 64, 64) == 0
     q = rnd(128, 3 * 96, seed=82)
     o = torch.empty(128, 96, device=DEV, dtype=BF)
-    assert lib.lmod_attn_fwd(q.data_ptr(), q.data_ptr(), q.data_ptr(), o.data_ptr(), None, None, 1, 128, 1, 1, 96, 288, 288, 288,
+    assert lib.lmod_attn_fwd(q.data_ptr(), q.data_ptr(), q.data_ptr(), o.data_ptr(), None, None, None, 1, 128, 1, 1, 96, 288, 288, 288,
                              96, 0.1, 1, s) == -3                       # head dim 96 is not compiled
     with pytest.raises(RuntimeError, match="LMOD_EINVAL"):
         K.gemm_nt(rnd(8, 12, seed=83), rnd(8, 12, seed=84))             # K = 12 through the binding
@@ -807,3 +807,43 @@ def test_residual_moe_layer_vs_oracle():
     close(xh.grad, xo.grad.to(DEV), "residual moe dx", rtol=2 ** -5, afrac=2 ** -6)
     for (n, p), (_, po) in zip(layer.named_parameters(), olayer.named_parameters()):
         close(p.main_grad, po.grad.to(DEV), f"residual moe grad {n}", rtol=2 ** -5, afrac=2 ** -5)
+
+
+def test_attn_packed_varlen_equals_padded():
+    """cu_seqlens (unpadded) layout of the hd-128 attention kernels: forward and backward on packed ragged samples equal the
+    padded + key-masked launch on the same samples, row for row."""
+    B, S, nh, nkv, hd = 3, 700, 4, 2, 128
+    lens = [700, 333, 64]
+    ld = (nh + 2 * nkv) * hd
+    qkv = rnd(B * S, ld, seed=5)
+    do = rnd(B * S, nh * hd, seed=6)
+    sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    sc = 1 / math.sqrt(hd)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, sc, True, sl)
+    dqkv = torch.zeros_like(qkv)
+    K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd], dqkv[:, (nh + nkv) * hd:],
+               B, S, nh, nkv, hd, sc, True, sl)
+    keep = torch.cat([torch.arange(L, device=DEV) + b * S for b, L in enumerate(lens)])
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    pq = qkv[keep].contiguous()
+    pdo = do[keep].contiguous()
+    q2, k2, v2 = pq[:, :nh * hd], pq[:, nh * hd:(nh + nkv) * hd], pq[:, (nh + nkv) * hd:]
+    o2, lse2 = K.attn_fwd(q2, k2, v2, B, S, nh, nkv, hd, sc, True, None, cu=cu)
+    assert torch.equal(o2, o[keep])
+    for b, L in enumerate(lens):
+        assert torch.equal(lse2[b, :, :L], lse[b, :, :L])
+    d2 = torch.zeros_like(pq)
+    K.attn_bwd(q2, k2, v2, o2, pdo, lse2, d2[:, :nh * hd], d2[:, nh * hd:(nh + nkv) * hd], d2[:, (nh + nkv) * hd:],
+               B, S, nh, nkv, hd, sc, True, None, cu=cu)
+    # padded backward: gradients of padded query rows are garbage-free zeros only for K/V; compare the kept rows
+    assert torch.equal(d2[:, :nh * hd], dqkv[keep][:, :nh * hd])
+    # dK/dV of kept keys receive contributions from padded QUERY rows in the padded launch (q >= len attends keys < len):
+    # zero those contributions by re-running the padded launch with dO = 0 on padded rows
+    do_m = do.clone()
+    padrows = torch.ones(B * S, dtype=torch.bool, device=DEV); padrows[keep] = False
+    do_m[padrows] = 0
+    dq3 = torch.zeros_like(qkv)
+    K.attn_bwd(q, k, v, o, do_m, lse, dq3[:, :nh * hd], dq3[:, nh * hd:(nh + nkv) * hd], dq3[:, (nh + nkv) * hd:],
+               B, S, nh, nkv, hd, sc, True, sl)
+    close(d2[:, nh * hd:], dq3[keep][:, nh * hd:], "packed dK/dV", rtol=2 ** -7, afrac=2 ** -9)
