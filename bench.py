@@ -55,15 +55,26 @@ def moe_model_args(experts, k=2, ep_size=1):
                            num_experts=[experts])
 
 
-def synthetic_batch(B, seed, text_len=1473, response=512, vocab=151643):
-    """ids U[0,151643), one -200 at index 14, labels on the last `response` tokens."""
+def synthetic_batch(B, seed, text_len=1473, response=512, vocab=151643, ragged=False):
+    """ids U[0,151643), one -200 at index 14, labels on the last `response` tokens.
+    ragged: the §8(d) variant — text lengths U[600, 1473], right-padded, labels on each sample's own last `response` tokens."""
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(0, vocab, (B, text_len), generator=g)
     ids[:, 14] = -200
     labels = torch.full((B, text_len), -100, dtype=torch.long)
-    labels[:, -response:] = ids[:, -response:]
+    mask = torch.ones(B, text_len, dtype=torch.bool)
+    if ragged:
+        lens = torch.randint(600, text_len + 1, (B,), generator=g)
+        lens[0] = text_len                                    # the batch maximum stays 2048 after the splice
+        for b in range(B):
+            L = int(lens[b])
+            labels[b, L - response:L] = ids[b, L - response:L]
+            mask[b, L:] = False
+            ids[b, L:] = vocab                                # pad id (unused: stripped by the mask)
+    else:
+        labels[:, -response:] = ids[:, -response:]
     images = torch.randn(B, 3, 336, 336, generator=g).to(torch.bfloat16)
-    return dict(input_ids=ids, attention_mask=torch.ones(B, text_len, dtype=torch.bool), labels=labels, images=images)
+    return dict(input_ids=ids, attention_mask=mask, labels=labels, images=images)
 
 
 def mimic_tflop(t_layers=32, s_dense=12, s_moe=12, vit_layers=23, S=2048, head_rows=None, V=151936, E=4, k=2):
@@ -196,6 +207,10 @@ def main():
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient exchange (N>1)")
     ap.add_argument("--max-grad-norm", type=float, default=1.0, help="global-norm clipping (HF Trainer default 1.0); 0 = off")
     ap.add_argument("--experts", type=int, default=4)
+    ap.add_argument("--ragged", action="store_true", help="SURVEY §8(d) ragged variant: text lengths U[600,1473], right-padded")
+    ap.add_argument("--unpad", action="store_true",
+                    help="with --ragged: unpadded (cu_seqlens) execution — no padding rows in any kernel (the MoE gate then does "
+                         "not see padding rows either, unlike the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
                     help="auto: full-depth oracle step (same weights, loss compared with the GPU) when host RAM >= 96 GB")
@@ -227,6 +242,7 @@ def main():
         # both models load the same frozen CLIP checkpoint in the reference's recipe (one --image_tower flag): give the
         # random-init teacher tower the student's weights, which lets the trainer compute the image features once per batch
         teacher.get_image_tower().load_state_dict(student.get_image_tower().state_dict())
+    student.unpad = teacher.unpad = bool(args.unpad)
     student.train(); teacher.eval()
     n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
     gb = GradBuffer(student)
@@ -237,7 +253,7 @@ def main():
     if args.stage == "mimic":
         trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
                                                                         loss_type="kd_lm", moe_loss_enable=True))())
-        batches = [synthetic_batch(B, 1000 * rank + i) for i in range(max(2, A))]
+        batches = [synthetic_batch(B, 1000 * rank + i, ragged=args.ragged) for i in range(max(2, A))]
     else:       # config 4: chosen / rejected pairs sharing the image; kto_pair is the shell default (preference_distillation.sh:29)
         from llavamod.train.dpo_trainer import DPOTrainer
         trainer = DPOTrainer(student, teacher, beta=0.1, loss_type="kto_pair")
@@ -343,6 +359,9 @@ def main():
                                     "config 4: preference distillation (kto_pair), value = chosen/rejected PAIRS per second") +
                                    f", CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({args.experts} experts, top-2, cf 1.5, 12 MoE layers, "
                                    f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
+                       "batch_shape": ("dense: every sample 2048 tokens" if not args.ragged else
+                                       "ragged: text lengths U[600,1473] right-padded (SURVEY 8d variant), " +
+                                       ("unpadded cu_seqlens execution" if args.unpad else "padded execution with key masks")),
                        "micro_batch_per_gpu": B, "grad_accum": A, "global_batch": B * A * world, "seq_len": 2048,
                        "response_tokens": 512, "parallelism": f"dp{world}",
                        "optimizer": ("fused AdamW once per step (fp32 master), global-norm clipping "
@@ -365,7 +384,7 @@ def main():
                                         "basis": f"{ledger:.2f} algorithmic TFLOP per unit (BASELINE.md) x units/s / n_gpus",
                                         "executed_tflop_per_sample": round(executed_tflop_per_sample(), 2)}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:
                 out["cpu_baseline"] = cpu_baseline(student, teacher, trainer if args.stage == "mimic" else None,
                                                    args.cpu_baseline if args.stage == "mimic" else "sample")

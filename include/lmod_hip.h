@@ -74,9 +74,11 @@ int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K
                       int accumulate, hipStream_t stream);
 
 /* out[C x ld_out] = in[R x C]^T, zero-filling columns R..ld_out-1 (makes dgrad / wgrad operands
- * K-contiguous for lmod_gemm_bf16_nt; autograd's implicit .t() in the reference). */
+ * K-contiguous for lmod_gemm_bf16_nt; autograd's implicit .t() in the reference).  r_valid (nullable, [batch]): live rows per batch entry (MoE capacity
+ * slabs): rows past it are not transposed at all — the k_valid GEMM that consumes the result never reads them — except that
+ * the 8-column group holding the boundary is zero-filled. */
 int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int ld_out, int batch,
-                        long long stride_in, long long stride_out, hipStream_t stream);
+                        long long stride_in, long long stride_out, const int* r_valid, hipStream_t stream);
 
 /* ---- row kernels -----------------------------------------------------------------------------
  * Qwen2RMSNorm (qwen2/modeling_qwen2.py:83-97) with the decoder layer's residual add fused
@@ -89,6 +91,12 @@ int lmod_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out,
 int lmod_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dh,
                      int T, int H, hipStream_t stream);
 /* nn.LayerNorm forward of the frozen CLIP tower (clip_encoder.py:45 runs under no_grad). */
+/* Weight gradients of the row parameters (only when they are trainable; the distillation shells freeze them):
+ * lmod_rmsnorm_dw: dw[H] (+)= sum_t dy[t,:] * bf16(h[t,:] * rstd[t])  (Qwen2RMSNorm.weight; deterministic; workspace 64*H floats);
+ * lmod_embed_wgrad: dW[idx[r], :] += d_embeds[r, :] for idx[r] >= 0  (embed_tokens.weight through the splice map; fp32 atomics). */
+int lmod_rmsnorm_dw(const void* dy, const void* h, const float* rstd, float* dw, float* workspace, int T, int H,
+                    int accumulate, hipStream_t stream);
+int lmod_embed_wgrad(const void* d_embeds, const int* idx, float* dW, long long rows, int H, hipStream_t stream);
 int lmod_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int T, int H, float eps,
                        hipStream_t stream);
 /* apply_rotary_pos_emb (qwen2/modeling_qwen2.py:146-171), in place on the first `nheads` heads

@@ -1125,13 +1125,18 @@ __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[
 
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                             int R, int C, int ld_in, int ld_out,
-                                                            long long s_in, long long s_out, int tiles_c) {
+                                                            long long s_in, long long s_out, int tiles_c,
+                                                            const int* __restrict__ r_valid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bz = blockIdx.y;
   const int tile = blockIdx.x * 4 + wave;               // one 64x64 tile per wave
   const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
   const int r0 = tr * 64 + (lane >> 3) * 8, c0 = tc * 64 + (lane & 7) * 8;
   if (c0 >= C || r0 >= ld_out) return;
+  if (r_valid) {       // grouped (MoE capacity slab) use: rows past the live count are never read by the k_valid GEMM —
+    R = min(R, r_valid[bz]);                            // only the 8-column group holding the boundary is zero-filled
+    if (r0 >= ((R + 7) & ~7)) return;
+  }
   const bf16_t* ip = in + (long long)bz * s_in;
   bf16_t* op = out + (long long)bz * s_out;
   u32x4 a[8], b[8];
@@ -1385,7 +1390,7 @@ int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K
 }
 
 int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int ld_out,
-                        int batch, long long stride_in, long long stride_out, hipStream_t stream) {
+                        int batch, long long stride_in, long long stride_out, const int* r_valid, hipStream_t stream) {
   if (!in || !out || R < 0 || C < 0) return LMOD_EINVAL;
   if (R == 0 || C == 0 || batch == 0) return LMOD_OK;
   if ((C & 7) || (ld_in & 7) || (ld_out & 7) || ld_in < C || ld_out < ((R + 7) & ~7)) return LMOD_EINVAL;
@@ -1393,7 +1398,7 @@ int lmod_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int 
   const int tiles_r = (ld_out + 63) / 64, tiles_c = (C + 63) / 64;
   const int tiles = tiles_r * tiles_c;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, stream,
-                     (const bf16_t*)in, (bf16_t*)out, R, C, ld_in, ld_out, stride_in, stride_out, tiles_c);
+                     (const bf16_t*)in, (bf16_t*)out, R, C, ld_in, ld_out, stride_in, stride_out, tiles_c, r_valid);
   return lmod_launch_status();
 }
 

@@ -380,6 +380,50 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const bf16_t* __restrict
 
 // ------------------------------------------------------------------ fused AdamW (decoupled decay)
 // fp32 master/m/v, fp32 grad, bf16 working copy refreshed in the same pass.
+// ---------------------------------------------------------------- weight gradients of the "row" parameters
+// RMSNorm scale (Qwen2RMSNorm, qwen2/modeling_qwen2.py:92-97: y = w * bf16(h * rstd)):  dw[c] = sum_t dy[t,c] * bf16(h[t,c] rstd[t]).
+// Deterministic two-stage column reduction: NSPLIT row slices -> partials[NSPLIT][H] -> fixed-order sum (+= dw).
+// Only runs when a norm scale is trainable (the distillation shells freeze them).
+#define DW_NSPLIT 64
+__global__ __launch_bounds__(256) void rmsnorm_dw_partial_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
+                                                                const float* __restrict__ rstd, float* __restrict__ part,
+                                                                int T, int H) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;           // a bf16 pair per thread: 1 KiB contiguous per row and block
+  if (c >= H) return;
+  float a0 = 0.f, a1 = 0.f;
+  for (int t = blockIdx.y; t < T; t += DW_NSPLIT) {
+    const uint32_t d = *(const uint32_t*)(dy + (long long)t * H + c), x = *(const uint32_t*)(h + (long long)t * H + c);
+    const float r = rstd[t];
+    a0 += bflo(d) * bfround(bflo(x) * r);
+    a1 += bfhi(d) * bfround(bfhi(x) * r);
+  }
+  part[(long long)blockIdx.y * H + c] = a0;
+  part[(long long)blockIdx.y * H + c + 1] = a1;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nsplit, int H,
+                                                          int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= H) return;
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += part[(long long)s * H + c];
+  out[c] = accumulate ? out[c] + a : a;
+}
+// Embedding table (embed_tokens): dW[idx[r], :] += d_embeds[r, :] for idx[r] >= 0 (text rows of the spliced sequence).
+// fp32 atomics: repeated token ids collide, so the summation ORDER is not fixed run to run (values agree to fp32 rounding).
+__global__ __launch_bounds__(256) void embed_wgrad_kernel(const bf16_t* __restrict__ d, const int* __restrict__ idx,
+                                                         float* __restrict__ dW, long long rows, int H) {
+  const int nch = H >> 1;
+  const long long total = rows * nch;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const long long r = id / nch; const int c = (int)(id - r * nch) * 2;
+    const int ix = idx[r];
+    if (ix < 0) continue;
+    const uint32_t v = *(const uint32_t*)(d + r * H + c);
+    unsafeAtomicAdd(dW + (long long)ix * H + c, bflo(v));
+    unsafeAtomicAdd(dW + (long long)ix * H + c + 1, bfhi(v));
+  }
+}
+
 // Matches torch.optim.AdamW (HF `adamw_torch`, reference config/args.py:78) step arithmetic.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, bf16_t* __restrict__ param,
                                                    float* __restrict__ grad, float* __restrict__ m,
@@ -479,6 +523,24 @@ int lmod_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* 
   if (T == 0) return LMOD_OK;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, (const bf16_t*)dy,
                      (const bf16_t*)h, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dh, T, H);
+  return lmod_launch_status();
+}
+
+int lmod_rmsnorm_dw(const void* dy, const void* h, const float* rstd, float* dw, float* workspace, int T, int H,
+                    int accumulate, hipStream_t stream) {
+  if (!dy || !h || !rstd || !dw || !workspace || T < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
+  if (T == 0) return LMOD_OK;
+  hipLaunchKernelGGL(rmsnorm_dw_partial_kernel, dim3((H / 2 + 255) / 256, DW_NSPLIT), dim3(256), 0, stream, (const bf16_t*)dy,
+                     (const bf16_t*)h, rstd, workspace, T, H);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, workspace, dw, min(DW_NSPLIT, T), H, accumulate);
+  return lmod_launch_status();
+}
+
+int lmod_embed_wgrad(const void* d_embeds, const int* idx, float* dW, long long rows, int H, hipStream_t stream) {
+  if (!d_embeds || !idx || !dW || rows < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
+  if (rows == 0) return LMOD_OK;
+  hipLaunchKernelGGL(embed_wgrad_kernel, dim3(grid_for(rows * (H >> 1))), dim3(256), 0, stream, (const bf16_t*)d_embeds, idx, dW,
+                     rows, H);
   return lmod_launch_status();
 }
 

@@ -19,9 +19,11 @@ SIGNATURES = {
     "lmod_gemm_swiglu_bwd_bf16": "pppp" + "iiiiiii" + "iqqqq" + "p" + "p",
     "lmod_gemm_wgrad_bf16_nt": "ppp" + "iiiiii" + "i" + "pq" + "p",
     "lmod_gemm_bf16_tn": "ppp" + "iiiiii" + "iqqq" + "p" + "ii" + "p",
-    "lmod_transpose_bf16": "pp" + "iiii" + "iqq" + "p",
+    "lmod_transpose_bf16": "pp" + "iiii" + "iqq" + "p" + "p",
     "lmod_rmsnorm_fwd": "pppppp" + "iif" + "p",
     "lmod_rmsnorm_bwd": "pppppp" + "ii" + "p",
+    "lmod_rmsnorm_dw": "pppp" + "p" + "iii" + "p",
+    "lmod_embed_wgrad": "ppp" + "qi" + "p",
     "lmod_layernorm_fwd": "pppp" + "iif" + "p",
     "lmod_rope": "pppp" + "iiiii" + "p",
     "lmod_swiglu_fwd": "ppp" + "qiiii" + "ip" + "p",

@@ -87,13 +87,17 @@ class GradBuffer:
         # needed because MoE modules are visited before their expert children in model.modules().
         for n, p in model.named_parameters():
             if p.requires_grad and id(p) not in covered:
-                # norm scales, the embedding table and the CLIP tower have no weight-gradient kernel on this path (the
-                # distillation shells freeze them: dense2sparse_distillation.sh train_modules); fail loudly, not silently
-                if not (n.endswith("wg.weight") or "wg." in n or "coefficient." in n):
+                # parameters without a fused weight: router, Residual-MoE head, decoder norm scales, the embedding table
+                # (all with a weight-gradient kernel).  Anything else (the CLIP tower, which the reference keeps frozen under
+                # no_grad, clip_encoder.py:31,45) has no gradient on this path: fail loudly, not silently.
+                ok = (n.endswith("wg.weight") or "wg." in n or "coefficient." in n or n.endswith("embed_tokens.weight")
+                      or (("layernorm.weight" in n or n.endswith("model.norm.weight") or n.endswith(".norm.weight"))
+                          and "image_tower" not in n))
+                if not ok:
                     raise NotImplementedError(
                         f"parameter {n!r} is marked trainable but this path computes no gradient for it (supported: "
-                        f"attention / MLP / expert / projector / lm_head linears, the MoE router and the Residual-MoE coefficient head); freeze it or list "
-                        f"only supported modules in train_modules")
+                        f"attention / MLP / expert / projector / lm_head linears, MoE router, Residual-MoE coefficient head, decoder "
+                        f"norm scales, embed_tokens); freeze it or list only supported modules in train_modules")
                 spans.append(("p", p, p.numel()))
                 covered.add(id(p))
         # dense (replicated) parameters first, expert-parallel-sharded expert weights last: two contiguous regions

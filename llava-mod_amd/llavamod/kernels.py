@@ -116,8 +116,9 @@ def gemm_tn(a, b, out=None, out_f32=True, accumulate=False, k_valid=None, K=None
     return out
 
 
-def transpose(x, ld_out=None, out=None):
-    """[.., R, C] -> [.., C, roundup(R,8)] (zero padded)."""
+def transpose(x, ld_out=None, out=None, r_valid=None):
+    """[.., R, C] -> [.., C, roundup(R,8)] (zero padded).  r_valid (int32 [batch]): live rows per batch entry; columns past
+    roundup(r_valid, 8) of the result are left untouched (a k_valid GEMM never reads them)."""
     R, C = x.shape[-2], x.shape[-1]
     batch = x.shape[0] if x.dim() == 3 else 1
     if ld_out is None:
@@ -126,7 +127,7 @@ def transpose(x, ld_out=None, out=None):
         shape = (batch, C, ld_out) if x.dim() == 3 else (C, ld_out)
         out = torch.empty(shape, device=x.device, dtype=BF16)
     call("lmod_transpose_bf16", ptr(x), ptr(out), R, C, x.stride(-2), ld_out, batch,
-         x.stride(0) if x.dim() == 3 else 0, out.stride(0) if out.dim() == 3 else 0)
+         x.stride(0) if x.dim() == 3 else 0, out.stride(0) if out.dim() == 3 else 0, ptr(r_valid))
     return out
 
 
@@ -145,6 +146,18 @@ def rmsnorm_bwd(dy, h, w, rstd, dres=None):
     dh = torch.empty_like(h)
     call("lmod_rmsnorm_bwd", ptr(dy), ptr(h), ptr(w), ptr(rstd), ptr(dres), ptr(dh), T, H)
     return dh
+
+
+def rmsnorm_dw(dy, h, rstd, dw, accumulate=True):
+    T, H = h.shape
+    ws = torch.empty(64 * H, device=h.device, dtype=torch.float32)
+    call("lmod_rmsnorm_dw", ptr(dy), ptr(h), ptr(rstd), ptr(dw), ptr(ws), T, H, int(accumulate))
+    return dw
+
+
+def embed_wgrad(d_embeds, idx, dW):
+    call("lmod_embed_wgrad", ptr(d_embeds), ptr(idx), ptr(dW), d_embeds.shape[0], d_embeds.shape[1])
+    return dW
 
 
 def layernorm_fwd(x, w, b, eps):

@@ -123,8 +123,7 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
                 dev = self.model.embed_tokens.weight.device
                 B, S = input_ids.shape
                 idx = input_ids.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
-                inputs_embeds = K.gather_rows(self.model.embed_tokens.weight, None, idx,
-                                              self.model.embed_tokens.weight.shape[1]).view(B, S, -1)
+                inputs_embeds = ops.SpliceEmbed.apply(None, self.model.embed_tokens.weight, idx, None).view(B, S, -1)
         else:
             plan = None
         B, S, H = inputs_embeds.shape

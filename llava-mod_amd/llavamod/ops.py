@@ -194,7 +194,12 @@ class AddRMSNorm(torch.autograd.Function):
         h, w, rstd = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(h)
-        g = K.rmsnorm_bwd(dy.contiguous(), h, w, rstd, dres=dh.contiguous() if dh is not None else None)
+        dy = dy.contiguous()
+        if w.requires_grad:                    # trainable norm scale (not in the distillation shells): fp32 main_grad += dw
+            if getattr(w, "main_grad", None) is None:
+                w.main_grad = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
+            K.rmsnorm_dw(dy, h, rstd, w.main_grad, accumulate=True)
+        g = K.rmsnorm_bwd(dy, h, w, rstd, dres=dh.contiguous() if dh is not None else None)
         return g, (g if ctx.has_res else None), None, None
 
 
@@ -357,21 +362,29 @@ class ProjectorBlock(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ splice
 class SpliceEmbed(torch.autograd.Function):
-    """inputs_embeds[B*S', H] = rows gathered from the (frozen) embedding table and the projector output
-    according to a host-built index map (llava_arch.py:236-318).  Backward routes rows to the projector."""
+    """inputs_embeds[B*S', H] = rows gathered from the embedding table and the projector output according to an index
+    map (llava_arch.py:236-318).  Backward routes image rows to the projector and, when the table is trainable, scatter-adds
+    the text rows into its fp32 main_grad.  img_feats / inv_idx None: plain embedding lookup (text-only batch)."""
 
     @staticmethod
     def forward(ctx, img_feats, embed_w, idx, inv_idx):
         H = embed_w.shape[1]
         out = K.gather_rows(embed_w, img_feats, idx, H)
-        ctx.save_for_backward(inv_idx)
-        ctx.H = H
+        ctx.save_for_backward(inv_idx, idx)
+        ctx.H, ctx.embed_w = H, embed_w
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (inv_idx,) = ctx.saved_tensors
-        return K.gather_rows(dout.contiguous(), None, inv_idx, ctx.H), None, None, None
+        inv_idx, idx = ctx.saved_tensors
+        dout = dout.contiguous()
+        ew = ctx.embed_w
+        if ew.requires_grad:                   # trainable embedding table (not in the distillation shells)
+            if getattr(ew, "main_grad", None) is None:
+                ew.main_grad = torch.zeros(ew.shape, device=ew.device, dtype=torch.float32)
+            K.embed_wgrad(dout, idx, ew.main_grad)
+        dfeats = K.gather_rows(dout, None, inv_idx, ctx.H) if (inv_idx is not None and ctx.needs_input_grad[0]) else None
+        return dfeats, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ MoE
@@ -419,8 +432,8 @@ class MoEBlock(torch.autograd.Function):
             dout = torch.zeros_like(x)
         dy, dw1, dw2 = K.moe_combine_bwd(dout.contiguous(), y.view(E * C, H), st, H)   # dy: zero rows on empty slots
         if sp.down.requires_grad:
-            K.gemm_nt(K.transpose(dy.view(E, C, H)), K.transpose(act), out=sp.down.grad_buffer(), out_f32=True,
-                      accumulate=True, k_valid=rows)
+            K.gemm_nt(K.transpose(dy.view(E, C, H), r_valid=rows), K.transpose(act, r_valid=rows), out=sp.down.grad_buffer(),
+                      out_f32=True, accumulate=True, k_valid=rows)
             sp.down.grad_done()
         if I % 16 == 0:      # grouped down dgrad + SwiGLU backward in one launch (dead rows: zeroed up to the next 8)
             dgu = K.gemm_swiglu_bwd(dy.view(E, C, H), sp.down.transposed(), gu, m_valid=rows, K=H)
@@ -434,8 +447,8 @@ class MoEBlock(torch.autograd.Function):
         d_in = torch.empty((E, C, H), device=x.device, dtype=BF16)
         K.gemm_nt(dgu, sp.gu.transposed(), out=d_in, m_valid=rows)
         if sp.gu.requires_grad:
-            K.gemm_nt(K.transpose(dgu), K.transpose(disp.view(E, C, H)), out=sp.gu.grad_buffer(), out_f32=True,
-                      accumulate=True, k_valid=rows)
+            K.gemm_nt(K.transpose(dgu, r_valid=rows), K.transpose(disp.view(E, C, H), r_valid=rows), out=sp.gu.grad_buffer(),
+                      out_f32=True, accumulate=True, k_valid=rows)
             sp.gu.grad_done()
         dlogits = K.moe_gate_bwd(st, dw1, dw2, dlaux.contiguous().float() if dlaux is not None else None)
         if sp.wg.requires_grad:

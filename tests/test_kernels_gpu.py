@@ -283,6 +283,45 @@ def test_rmsnorm_fwd_bwd(T, H):
     close(dh, hh.grad + dres.float(), "rmsnorm bwd", rtol=2 ** -6, afrac=2 ** -7)
 
 
+@pytest.mark.parametrize("T,H", [(1, 64), (63, 136), (1000, 2048), (4097, 4096)])
+def test_rmsnorm_scale_gradient(T, H):
+    """dw[c] = sum_t dy[t,c] * bf16(h[t,c] * rstd[t]) (Qwen2RMSNorm, modeling_qwen2.py:92-97) vs the fp32 sum; accumulates into
+    an fp32 buffer, deterministic (two launches give identical bits)."""
+    h, dy = rnd(T, H, seed=11), rnd(T, H, seed=12)
+    rstd = torch.rsqrt(h.float().pow(2).mean(-1) + 1e-6).contiguous()
+    ref = (dy.double() * (h.float() * rstd[:, None]).to(BF).double()).sum(0)
+    base = torch.randn(H, device=DEV)
+    dw = base.clone()
+    K.rmsnorm_dw(dy, h, rstd, dw, accumulate=True)
+    err = (dw.double() - base.double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item() + 1e-6 * (T ** 0.5), err
+    dw2 = torch.full((H,), 7.0, device=DEV)
+    K.rmsnorm_dw(dy, h, rstd, dw2, accumulate=False)
+    dw3 = torch.empty(H, device=DEV)
+    K.rmsnorm_dw(dy, h, rstd, dw3, accumulate=False)
+    assert torch.equal(dw2, dw3)
+    assert (dw2.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6 * (T ** 0.5)
+
+
+def test_embedding_gradient_scatter_add():
+    """dW[idx[r]] += d_embeds[r] for text rows (idx >= 0); image rows (idx <= -2) and padding (-1) do not touch the table."""
+    V, H, R = 300, 136, 5000
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, V, (R,), generator=g).to(torch.int32)
+    idx[torch.rand(R, generator=g) < 0.3] = -1
+    idx[torch.rand(R, generator=g) < 0.2] = -7
+    idx[:40] = 3                                               # heavy collisions on one row
+    d = rnd(R, H, seed=6)
+    dW = torch.zeros(V, H, device=DEV)
+    K.embed_wgrad(d, idx.to(DEV), dW)
+    ref = torch.zeros(V, H, dtype=torch.float64)
+    keep = idx >= 0
+    ref.index_add_(0, idx[keep].long(), d.cpu().double()[keep])
+    assert (dW.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    K.embed_wgrad(d, idx.to(DEV), dW)                          # accumulates
+    assert (dW.cpu().double() - 2 * ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_layernorm_fwd():
     T, H = 37, 1024
     x, w, b = rnd(T, H, seed=1), rnd(H, seed=2), rnd(H, seed=3)

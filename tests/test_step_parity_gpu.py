@@ -367,6 +367,58 @@ def test_finetune_student_and_top1_step():
     _check_grads(_grads_of(s1), ograds, 3e-2, 5e-2)
 
 
+def test_trainable_norms_and_embedding_step():
+    """A run that unfreezes the decoder's RMSNorm scales and embed_tokens (not the distillation shells' train_modules, but
+    reachable through --train_modules / FineTune): their gradients come from lmod_rmsnorm_dw / lmod_embed_wgrad and match the
+    oracle's, alongside the usual set; a parameter with no gradient kernel (CLIP tower) raises at GradBuffer construction."""
+    from llavamod.engine import GradBuffer
+    from llavamod.train.align_trainer import AlignTrainer
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    extra = ("layernorm.weight", "model.norm.weight", "embed_tokens.weight")
+    for n, p in student.named_parameters():
+        if any(n.endswith(e) for e in extra) and "image_tower" not in n:
+            p.requires_grad = True
+    for m in student.moe_layers():
+        m.deterministic = True
+    gb = GradBuffer(student)
+    o_student, o_teacher = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
+    o_student.load_state_dict(ssd); o_teacher.load_state_dict(tsd)
+    freeze_like_d2s(o_student)
+    for n, p in o_student.named_parameters():
+        if any(n.endswith(e) for e in extra) and "image_tower" not in n:
+            p.requires_grad_(True)
+    ob = {k: g["ragged_kdlm.batch." + k] for k in ("input_ids", "attention_mask", "labels", "images")}
+    ob["attention_mask"] = ob["attention_mask"].bool()
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None])
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, ob, loss_type="kd_lm", align_vocab=512)
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False, loss_type="kd_lm",
+                                                               moe_loss_enable=True))(), align_vocab=512)
+    student.train(); gb.zero()
+    loss, outs = tr.compute_loss(student, _batch_from(g, "ragged_kdlm"), return_outputs=True)
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= 1e-3 * abs(float(loss_o))
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    hgrads = _grads_of(student)
+    assert set(ograds) == set(hgrads), sorted(set(ograds) ^ set(hgrads))[:8]
+    new = [n for n in ograds if any(n.endswith(e) for e in extra)]
+    assert len(new) == 2 * sc.num_hidden_layers + 2
+    _check_grads(hgrads, ograds, 3e-2, 5e-2)
+    # second backward accumulates (gradient accumulation contract of main_grad)
+    before = {n: hgrads[n].clone() for n in new}
+    loss2 = tr.compute_loss(student, _batch_from(g, "ragged_kdlm"))
+    loss2.backward()
+    for n in new:
+        assert U.relerr(hgrads[n], 2 * before[n]) <= 1e-3, n
+    # no silent zero-gradient parameters: a trainable CLIP tower is refused
+    s2, _ = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
+    next(s2.get_image_tower().parameters()).requires_grad = True
+    with pytest.raises(NotImplementedError):
+        GradBuffer(s2)
+
+
 @pytest.mark.parametrize("loss_type", ["sigmoid", "kto_pair"])
 def test_seeded_mid_dpo_step_vs_oracle(loss_type):
     from llavamod.engine import GradBuffer
