@@ -677,6 +677,11 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
 }
 
 // delta_ws: [B, nh, S] fp32 workspace.  dQ/dK/dV use the same layouts as Q/K/V (own leading dims).
+static bool bwd_generic() {      // LMOD_ATTN_BWD=1: hd-128 backward through the generic 16x16x32 kernels (A/B timing, tests)
+  static const bool v = [] { const char* e = getenv("LMOD_ATTN_BWD"); return e && e[0] == '1'; }();
+  return v;
+}
+
 int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                   float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
                   int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
@@ -697,6 +702,10 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo, cu_seqlens);
+  if (hd == 128 && !bwd_generic()) {
+    lmod_launch_attn_bwd2(p, causal, stream);
+    return lmod_launch_status();
+  }
   constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;
   const int nqb = (S + QB - 1) / QB, nkb = (S + KBLK - 1) / KBLK;
   const dim3 gq(causal ? (nqb + 1) / 2 : nqb, nh, B), gk(causal ? (nkb + 1) / 2 : nkb, nkv, B);

@@ -1,0 +1,533 @@
+// Flash attention backward for head dim 128 on gfx950 (the autograd of qwen2/modeling_qwen2.py:700-708 / :290-309 that
+// the reference gets from torch SDPA / flash-attn): dQ in one kernel, dK + dV in another, from Q, K, V, dO, the forward's
+// log-sum-exp rows and delta = rowsum(dO * O).
+//
+// One workgroup = 4 waves = ONE wave per SIMD with the full 512-register file: 256 accumulator registers owned by inline
+// asm (attn_acc256.h) + 256 VGPRs.  A wave OWNS 64 rows (dK/dV kernel: 64 keys; dQ kernel: 64 queries) and streams the
+// other side in 32-row tiles through LDS; every operand fragment read from LDS feeds TWO MFMAs (the wave's two 32-row
+// owner strips), which halves the LDS traffic per flop of a 32-row-per-wave tiling (LDS pipe ~35 % busy at the MFMA rate).
+//
+//   owner side   X (K | Q): fragments in registers for the whole block (B operands, 64 VGPRs)
+//                Y (V | dO): 256-row image resident in LDS (272-byte rows: conflict-free ds_read_b128 with immediates only)
+//   streamed     Xs (Q | K), Ys (dO | V): 32-row tiles, double buffered, 320-byte rows with the 16-byte chunk index XORed by
+//                (row >> 3) & 3.  That one image serves BOTH read patterns without bank conflicts: ds_read_b128 operand rows
+//                (S, dP) and ds_read_b64_tr_b16 transposed fragments (dK/dV/dQ), see `rowa` / `tra`.
+//
+// MFMA 32x32x16 (operand index = lane&31, 8 reduction slots at (lane>>5)*8; D: column = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)):
+//   S  [t x o] = Xs X^T      dP [t x o] = Ys Y^T          (t: streamed row, o: owner row; a lane owns ONE owner row)
+//   P = exp2(S c - lse),  dS = P (dP - delta);  packed to bf16 in place they ARE the B operands of
+//   accY [d x o] += Ys^T P   (dV^T;  dK/dV kernel only)   accX [d x o] += Xs^T dS   (dK^T | dQ^T)
+//   — the reduction-slot order of an MFMA is free when both operands agree, so no LDS round trip and no cross-lane move.
+// Schedule per 32-row tile (dK/dV: 64 MFMAs; dQ: 48), all VALU work placed in the shadow of MFMAs whose inputs are ready:
+//   dK/dV:  S (16)  |  dP (16) || exp2, pack P  |  dV += (16) || dS, pack  |  dK += (16) || LDS writes of the next tile
+//   dQ:     dP (16) |  S strip 0 (8) || dP -= delta  |  S strip 1 (8) || strip 0: exp2, dS, pack
+//                   |  dQ strip 0 += (8) || strip 1: exp2, dS, pack  |  dQ strip 1 += (8)
+// One workgroup barrier per tile.  Built by hipcc_agpr.sh with "amdgpu-agpr-alloc"="256".
+#include "attn_common.h"
+#include "attn_acc256.h"
+#include <type_traits>
+
+#define B2_PITCH 320
+#define B2_TILE (32 * B2_PITCH)            // one streamed tensor's tile image
+#define B2_LD (2 * B2_TILE)                // lse2[32], delta[32] of the tile (dK/dV kernel)
+#define B2_BUF (2 * B2_TILE + 256)
+#define B2_YPITCH 272
+#define B2_YIMG (256 * B2_YPITCH)
+#define B2_LDS (B2_YIMG + 2 * B2_BUF)
+#define B2_PIN(x) asm volatile("" : "+v"(x))
+#define B2_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef B2_DEPTH
+#define B2_DEPTH 2                         // operand fragments are read from LDS this many steps ahead
+#endif
+
+template <bool FIRST>
+__device__ __forceinline__ void sd_mfma(f32x16& acc, const bf16x8 a, const bf16x8 b) {
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b) : B2_CLOB_ALL);
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : B2_CLOB_ALL);
+}
+__device__ __forceinline__ bf16x8 tr2(const char* p0, const char* p1) {      // reduction slots 0-3 | 4-7
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <int N>
+__device__ __forceinline__ void store_strip(bf16_t* dst, const float mul) {   // 16 contiguous features of this lane's row
+  float v[16];
+  acc_read16<N>(v);
+  u32x4 w0, w1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w0[k] = pack2bf(v[2 * k] * mul, v[2 * k + 1] * mul);
+    w1[k] = pack2bf(v[8 + 2 * k] * mul, v[8 + 2 * k + 1] * mul);
+  }
+  *(u32x4*)(dst) = w0;
+  *(u32x4*)(dst + 8) = w1;
+}
+template <int I> using IC = std::integral_constant<int, I>;
+// MFMA result -> first VALU read.  hipcc does not see inside the asm MFMAs, so (a) it inserts no wait states and (b) it is free
+// to hoist the VALU consumers above them.  The pad is an asm statement that "modifies" the accumulators: every consumer is
+// data-dependent on it and it is itself ordered after the MFMAs (all asm volatile).  It is placed after the MFMAs of the step
+// FOLLOWING the producer's last one, so >= 1 full MFMA issue slot (32 cycles) has passed; the s_nop covers the rest.
+__device__ __forceinline__ void hazard_pad(f32x16& a, f32x16& b) {
+  asm volatile("s_nop 3" : "+v"(a), "+v"(b)::B2_CLOB_ALL);
+}
+__device__ __forceinline__ void hazard_pad(f32x16& a) { asm volatile("s_nop 3" : "+v"(a)::B2_CLOB_ALL); }
+
+template <bool DKV, bool CAUSAL>
+__device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, int ho, int b) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = p.cu ? (p.cu[b + 1] - p.cu[b]) : p.S;
+  const int len = p.seqlens ? min(p.seqlens[b], S) : S;
+  const int o0 = ob * 256, ow0 = o0 + wave * 64;
+  if (o0 >= S) return;
+  const long long tok0 = p.cu ? (long long)p.cu[b] : (long long)b * S;
+  const float c = p.scale * 1.4426950408889634f;
+  const int gsz = DKV ? p.group : 1;
+
+  const bf16_t* Xo = DKV ? p.K + tok0 * p.ldk + ho * 128 : p.Q + tok0 * p.ldq + ho * 128;
+  const bf16_t* Yo = DKV ? p.V + tok0 * p.ldv + ho * 128 : p.dO + tok0 * p.lddo + ho * 128;
+  const int ldxo = DKV ? p.ldk : p.ldq, ldyo = DKV ? p.ldv : p.lddo;
+  const bf16_t* Xs = DKV ? p.Q + tok0 * p.ldq + (ho * p.group) * 128 : p.K + tok0 * p.ldk + (ho / p.group) * 128;
+  const bf16_t* Ys = DKV ? p.dO + tok0 * p.lddo + (ho * p.group) * 128 : p.V + tok0 * p.ldv + (ho / p.group) * 128;
+  const int ldxs = DKV ? p.ldq : p.ldk, ldys = DKV ? p.lddo : p.ldv;
+
+  // ---- owner fragments X (B operands of S): row ow0 + 32*os + l31, features ks*16 + hi*8 .. +7
+  bf16x8 xf[2][8];
+  float olse[2] = {0.f, 0.f}, odl[2] = {0.f, 0.f};             // dQ kernel: the lane's own rows' lse (log2 units) and delta
+#pragma unroll
+  for (int os = 0; os < 2; ++os) {
+    const int row = ow0 + os * 32 + l31;
+    const bf16_t* xp = Xo + (long long)min(row, S - 1) * ldxo + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      xf[os][ks] = *(const bf16x8*)(xp + ks * 16);
+      if (row >= S) xf[os][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    if constexpr (!DKV) {
+      const long long si = ((long long)b * p.nh + ho) * p.S + min(row, S - 1);
+      olse[os] = p.LSE[si] * 1.4426950408889634f;
+      odl[os] = p.Delta[si];
+    }
+  }
+  // ---- owner image Y: rows o0 .. o0+255 (zeros past the end of the sequence) -> LDS, 272-byte rows
+  {
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yo, 0, (int)(((long long)(S - 1) * ldyo + 128) * 2), 0x00020000);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+      u32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * (bt * 4 + i), row = id >> 4, ch = id & 15;
+        v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (uint32_t)((o0 + row) * ldyo + ch * 8) * 2u, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * (bt * 4 + i), row = id >> 4, ch = id & 15;
+        *(u32x4*)(smem + row * B2_YPITCH + ch * 16) = v[i];
+      }
+    }
+  }
+  acc_zero_all();
+
+  // ---- streamed tiles
+  const int nt = DKV ? (S + 31) >> 5 : ((CAUSAL ? min(o0 + 256, len) : len) + 31) >> 5;
+  const int first = (DKV && CAUSAL) ? (o0 >> 5) : 0;
+  const int per_head = nt - first;
+  int total = per_head * gsz;
+  if (DKV && o0 >= len) total = 0;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xs, 0, (int)(((long long)(S - 1) * ldxs + gsz * 128) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rys = __builtin_amdgcn_make_buffer_rsrc((void*)Ys, 0, (int)(((long long)(S - 1) * ldys + gsz * 128) * 2), 0x00020000);
+  const int srow = tid >> 4, sch = tid & 15;                    // staging: rows srow and srow + 16, chunk sch
+  const uint32_t xg0 = (uint32_t)(srow * ldxs + sch * 8) * 2u, xg1 = xg0 + (uint32_t)(16 * ldxs) * 2u;
+  const uint32_t yg0 = (uint32_t)(srow * ldys + sch * 8) * 2u, yg1 = yg0 + (uint32_t)(16 * ldys) * 2u;
+  const int wa0 = B2_YIMG + srow * B2_PITCH + ((sch ^ ((srow >> 3) & 3)) << 4);
+  const int wa1 = B2_YIMG + (srow + 16) * B2_PITCH + ((sch ^ (((srow + 16) >> 3) & 3)) << 4);
+  u32x4 xr0, xr1, yr0, yr1;
+  float ldr = 0.f;
+  auto gload = [&](const int it) {
+    const int hh = it / per_head, j = first + it - hh * per_head;
+    const uint32_t ax = (uint32_t)(j * 32 * ldxs + hh * 128) * 2u, ay = (uint32_t)(j * 32 * ldys + hh * 128) * 2u;
+    xr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg0 + ax, 0, 0));
+    xr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg1 + ax, 0, 0));
+    yr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg0 + ay, 0, 0));
+    yr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg1 + ay, 0, 0));
+    if constexpr (DKV) {
+      if (tid < 64) {
+        const int t = j * 32 + (tid & 31);
+        const long long si = ((long long)b * p.nh + ho * p.group + hh) * p.S + min(t, S - 1);
+        const float v = (tid < 32) ? p.LSE[si] * 1.4426950408889634f : p.Delta[si];
+        ldr = (t < S) ? v : 0.f;
+      }
+    }
+  };
+  auto lwrite = [&](const int buf) {
+    char* bb = smem + buf * B2_BUF;
+    *(u32x4*)(bb + wa0) = xr0;
+    *(u32x4*)(bb + wa1) = xr1;
+    *(u32x4*)(bb + B2_TILE + wa0) = yr0;
+    *(u32x4*)(bb + B2_TILE + wa1) = yr1;
+    if constexpr (DKV) { if (tid < 64) *(float*)(bb + B2_YIMG + B2_LD + tid * 4) = ldr; }
+  };
+
+  // ---- operand read addresses (bytes from smem; immediates carry feature group, row group and tensor)
+  int rowa[2], tra[4];
+  {
+    const int hrow = (l31 >> 3) & 3;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) rowa[par] = B2_YIMG + l31 * B2_PITCH + (((2 * par + hi) ^ hrow) << 4);
+    const int i16 = lane & 15, gi = (lane >> 4) & 1, r4 = i16 >> 2, cc = i16 & 3;
+#pragma unroll
+    for (int hc = 0; hc < 4; ++hc) tra[hc] = B2_YIMG + (4 * hi + r4) * B2_PITCH + (((2 * (cc & 1) + gi) ^ hc) << 4) + 8 * (cc >> 1);
+  }
+  int lda = B2_YIMG + B2_LD + hi * 16;
+  const int ya = (wave * 64 + l31) * B2_YPITCH + hi * 16;
+
+  auto rd_xs = [&](const int ks) { return *(const bf16x8*)(smem + rowa[ks & 1] + (ks >> 1) * 64); };
+  auto rd_ys = [&](const int ks) { return *(const bf16x8*)(smem + rowa[ks & 1] + B2_TILE + (ks >> 1) * 64); };
+  auto rd_y = [&](const int os, const int ks) { return *(const bf16x8*)(smem + ya + os * 32 * B2_YPITCH + ks * 32); };
+  auto rd_tr = [&](const int tensor, const int tk, const int dt) {
+    return tr2(smem + tra[(2 * tk) & 3] + tensor * B2_TILE + (16 * tk) * B2_PITCH + dt * 64,
+               smem + tra[(2 * tk + 1) & 3] + tensor * B2_TILE + (16 * tk + 8) * B2_PITCH + dt * 64);
+  };
+
+  f32x16 s[2], dp[2];
+  uint32_t pP[2][8], pS[2][8];         // bf16-packed P and dS: [owner strip][4 * reduction step of 16 streamed rows + dword]
+
+  // p = exp2(s c - lse) of rows 4*G4 .. +3 of strip OS (masked entries -> 0); dK/dV kernel: packed into pP
+  auto exp_grp = [&](auto masked_t, auto os_t, auto g4_t, const int thr) {
+    constexpr bool MASKED = decltype(masked_t)::value;
+    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value;
+    f32x4 l4;
+    if constexpr (DKV) l4 = *(const f32x4*)(smem + lda + G4 * 32);
+    else l4 = (f32x4){olse[OS], olse[OS], olse[OS], olse[OS]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * G4 + e, base = (r & 3) + 8 * (r >> 2);
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[OS][r], c, -l4[e]));
+      if constexpr (MASKED) { if (DKV ? (base < thr) : (base > thr)) pv = 0.f; }
+      s[OS][r] = pv;
+    }
+    if constexpr (DKV) {
+      pP[OS][2 * G4] = pack2bf(s[OS][4 * G4], s[OS][4 * G4 + 1]);
+      pP[OS][2 * G4 + 1] = pack2bf(s[OS][4 * G4 + 2], s[OS][4 * G4 + 3]);
+      B2_PIN(pP[OS][2 * G4]); B2_PIN(pP[OS][2 * G4 + 1]);
+    } else {
+      B2_PIN(s[OS]);
+    }
+  };
+  // dS = p (dp - delta) of the same rows, packed into pS.  SUB: delta still to be subtracted
+  auto ds_grp = [&](auto sub_t, auto os_t, auto g4_t) {
+    constexpr bool SUB = decltype(sub_t)::value;
+    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value;
+    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SUB) {
+      if constexpr (DKV) d4 = *(const f32x4*)(smem + lda + 128 + G4 * 32);
+      else d4 = (f32x4){odl[OS], odl[OS], odl[OS], odl[OS]};
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * G4 + e;
+      v[e] = s[OS][r] * (SUB ? dp[OS][r] - d4[e] : dp[OS][r]);
+    }
+    pS[OS][2 * G4] = pack2bf(v[0], v[1]);
+    pS[OS][2 * G4 + 1] = pack2bf(v[2], v[3]);
+    B2_PIN(pS[OS][2 * G4]); B2_PIN(pS[OS][2 * G4 + 1]);
+  };
+  auto opnd = [](const uint32_t (&w)[8], const int tk) {
+    return __builtin_bit_cast(bf16x8, (u32x4){w[4 * tk], w[4 * tk + 1], w[4 * tk + 2], w[4 * tk + 3]});
+  };
+
+  // ================================================================================ dK/dV tile body
+  auto body_dkv = [&](auto masked_t, const int lo0, const int lo1) {
+    // ---- S = Xs X^T
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+        const bf16x8 a = af[ks % (B2_DEPTH + 1)];
+        if (ks == 0) { sd_mfma<true>(s[0], a, xf[0][0]); sd_mfma<true>(s[1], a, xf[1][0]); }
+        else { sd_mfma<false>(s[0], a, xf[0][ks]); sd_mfma<false>(s[1], a, xf[1][ks]); }
+        B2_SB();
+      }
+    }
+    // ---- dP = Ys Y^T  ||  P = exp2(S c - lse), packed
+    {
+      bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); b0[st] = rd_y(0, st); b1[st] = rd_y(1, st); }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
+        if (nx < 8) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
+        if (ks == 0) { sd_mfma<true>(dp[0], af[cu], b0[cu]); sd_mfma<true>(dp[1], af[cu], b1[cu]); }
+        else { sd_mfma<false>(dp[0], af[cu], b0[cu]); sd_mfma<false>(dp[1], af[cu], b1[cu]); }
+        if (ks == 0) hazard_pad(s[0], s[1]);
+        if (ks == 0) exp_grp(masked_t, IC<0>{}, IC<0>{}, lo0);
+        if (ks == 1) exp_grp(masked_t, IC<0>{}, IC<1>{}, lo0);
+        if (ks == 2) exp_grp(masked_t, IC<1>{}, IC<0>{}, lo1);
+        if (ks == 3) exp_grp(masked_t, IC<1>{}, IC<1>{}, lo1);
+        if (ks == 4) exp_grp(masked_t, IC<0>{}, IC<2>{}, lo0);
+        if (ks == 5) exp_grp(masked_t, IC<0>{}, IC<3>{}, lo0);
+        if (ks == 6) exp_grp(masked_t, IC<1>{}, IC<2>{}, lo1);
+        if (ks == 7) exp_grp(masked_t, IC<1>{}, IC<3>{}, lo1);
+        B2_SB();
+      }
+    }
+    // ---- dV^T += Ys^T P  ||  dS = P (dP - delta), packed
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(1, st >> 2, st & 3);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx >> 2, nx & 3);
+        const bf16x8 a = af[st % (B2_DEPTH + 1)];
+        if (dt == 0) { acc_mfma<8>(a, opnd(pP[0], tk)); acc_mfma<12>(a, opnd(pP[1], tk)); }
+        if (dt == 1) { acc_mfma<9>(a, opnd(pP[0], tk)); acc_mfma<13>(a, opnd(pP[1], tk)); }
+        if (dt == 2) { acc_mfma<10>(a, opnd(pP[0], tk)); acc_mfma<14>(a, opnd(pP[1], tk)); }
+        if (dt == 3) { acc_mfma<11>(a, opnd(pP[0], tk)); acc_mfma<15>(a, opnd(pP[1], tk)); }
+        if (st == 0) hazard_pad(dp[0], dp[1]);
+        using T = BoolTag<true>;
+        if (st == 0) ds_grp(T{}, IC<0>{}, IC<0>{});
+        if (st == 1) ds_grp(T{}, IC<0>{}, IC<1>{});
+        if (st == 2) ds_grp(T{}, IC<1>{}, IC<0>{});
+        if (st == 3) ds_grp(T{}, IC<1>{}, IC<1>{});
+        if (st == 4) ds_grp(T{}, IC<0>{}, IC<2>{});
+        if (st == 5) ds_grp(T{}, IC<0>{}, IC<3>{});
+        if (st == 6) ds_grp(T{}, IC<1>{}, IC<2>{});
+        if (st == 7) ds_grp(T{}, IC<1>{}, IC<3>{});
+        B2_SB();
+      }
+    }
+    // ---- dK^T += Xs^T dS
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+        const bf16x8 a = af[st % (B2_DEPTH + 1)];
+        if (dt == 0) { acc_mfma<0>(a, opnd(pS[0], tk)); acc_mfma<4>(a, opnd(pS[1], tk)); }
+        if (dt == 1) { acc_mfma<1>(a, opnd(pS[0], tk)); acc_mfma<5>(a, opnd(pS[1], tk)); }
+        if (dt == 2) { acc_mfma<2>(a, opnd(pS[0], tk)); acc_mfma<6>(a, opnd(pS[1], tk)); }
+        if (dt == 3) { acc_mfma<3>(a, opnd(pS[0], tk)); acc_mfma<7>(a, opnd(pS[1], tk)); }
+        B2_SB();
+      }
+    }
+  };
+
+  // ================================================================================ dQ tile body
+  auto body_dq = [&](auto masked_t, const int up0, const int up1) {
+    using T = BoolTag<true>;
+    using F = BoolTag<false>;
+    // ---- dP = Ys Y^T   (Ys = V rows, Y = dO image)
+    {
+      bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); b0[st] = rd_y(0, st); b1[st] = rd_y(1, st); }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
+        if (nx < 8) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
+        if (ks == 0) { sd_mfma<true>(dp[0], af[cu], b0[cu]); sd_mfma<true>(dp[1], af[cu], b1[cu]); }
+        else { sd_mfma<false>(dp[0], af[cu], b0[cu]); sd_mfma<false>(dp[1], af[cu], b1[cu]); }
+        B2_SB();
+      }
+    }
+    // ---- S strip 0  ||  dP -= delta ; S strip 1  ||  strip 0: exp2, dS, pack    (K row fragments are read twice)
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+        const bf16x8 a = af[ks % (B2_DEPTH + 1)];
+        if (ks == 0) sd_mfma<true>(s[0], a, xf[0][0]); else sd_mfma<false>(s[0], a, xf[0][ks]);
+        if (ks == 0) hazard_pad(dp[0], dp[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int os = ks >> 2, r = (ks & 3) * 4 + e;
+          dp[os][r] -= odl[os];
+        }
+        B2_PIN(dp[ks >> 2]);
+        B2_SB();
+      }
+    }
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+        const bf16x8 a = af[ks % (B2_DEPTH + 1)];
+        if (ks == 0) sd_mfma<true>(s[1], a, xf[1][0]); else sd_mfma<false>(s[1], a, xf[1][ks]);
+        if (ks == 0) hazard_pad(s[0]);
+        if (ks == 0) exp_grp(masked_t, IC<0>{}, IC<0>{}, up0);
+        if (ks == 1) { ds_grp(F{}, IC<0>{}, IC<0>{}); exp_grp(masked_t, IC<0>{}, IC<1>{}, up0); }
+        if (ks == 2) ds_grp(F{}, IC<0>{}, IC<1>{});
+        if (ks == 3) exp_grp(masked_t, IC<0>{}, IC<2>{}, up0);
+        if (ks == 4) ds_grp(F{}, IC<0>{}, IC<2>{});
+        if (ks == 5) exp_grp(masked_t, IC<0>{}, IC<3>{}, up0);
+        if (ks == 6) ds_grp(F{}, IC<0>{}, IC<3>{});
+        B2_SB();
+      }
+    }
+    // ---- dQ^T strip 0 += K^T dS  ||  strip 1: exp2, dS, pack ; then strip 1
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+        const bf16x8 a = af[st % (B2_DEPTH + 1)];
+        if (dt == 0) acc_mfma<0>(a, opnd(pS[0], tk));
+        if (dt == 1) acc_mfma<1>(a, opnd(pS[0], tk));
+        if (dt == 2) acc_mfma<2>(a, opnd(pS[0], tk));
+        if (dt == 3) acc_mfma<3>(a, opnd(pS[0], tk));
+        if (st == 0) hazard_pad(s[1]);
+        if (st == 0) exp_grp(masked_t, IC<1>{}, IC<0>{}, up1);
+        if (st == 1) { ds_grp(F{}, IC<1>{}, IC<0>{}); exp_grp(masked_t, IC<1>{}, IC<1>{}, up1); }
+        if (st == 2) ds_grp(F{}, IC<1>{}, IC<1>{});
+        if (st == 3) exp_grp(masked_t, IC<1>{}, IC<2>{}, up1);
+        if (st == 4) ds_grp(F{}, IC<1>{}, IC<2>{});
+        if (st == 5) exp_grp(masked_t, IC<1>{}, IC<3>{}, up1);
+        if (st == 6) ds_grp(F{}, IC<1>{}, IC<3>{});
+        B2_SB();
+      }
+    }
+    {
+      bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+        const bf16x8 a = af[st % (B2_DEPTH + 1)];
+        if (dt == 0) acc_mfma<4>(a, opnd(pS[1], tk));
+        if (dt == 1) acc_mfma<5>(a, opnd(pS[1], tk));
+        if (dt == 2) acc_mfma<6>(a, opnd(pS[1], tk));
+        if (dt == 3) acc_mfma<7>(a, opnd(pS[1], tk));
+        B2_SB();
+      }
+    }
+  };
+
+  // ---- prologue
+  if (total > 0) { gload(0); lwrite(0); }
+  __syncthreads();
+
+  for (int it = 0; it < total; ++it) {
+    const int hh = it / per_head, j = first + it - hh * per_head, t0 = j * 32;
+    const bool more = it + 1 < total;
+    if (more) gload(it + 1);
+    bool skip, masked;
+    int th0, th1;
+    if constexpr (DKV) {
+      // valid(streamed query row, owner key): key < len and (non-causal or row >= key); rows past S carry zero dO / delta
+      skip = CAUSAL && t0 + 31 < ow0;
+      masked = (CAUSAL && t0 < ow0 + 63) || ow0 + 64 > len;
+      const int k0 = ow0 + l31, k1 = k0 + 32;
+      th0 = (k0 >= len) ? 1000 : (CAUSAL ? k0 - t0 - 4 * hi : -1000);      // row index inside the tile must be >= th
+      th1 = (k1 >= len) ? 1000 : (CAUSAL ? k1 - t0 - 4 * hi : -1000);
+    } else {
+      // valid(streamed key row, owner query): key < len and (non-causal or key <= query)
+      skip = (CAUSAL && t0 > ow0 + 63) || ow0 >= S;
+      masked = (CAUSAL && t0 + 31 > ow0) || t0 + 32 > len;
+      const int q0 = ow0 + l31, q1 = q0 + 32;
+      th0 = (CAUSAL ? min(len - 1, q0) : len - 1) - t0 - 4 * hi;             // row index inside the tile must be <= th
+      th1 = (CAUSAL ? min(len - 1, q1) : len - 1) - t0 - 4 * hi;
+    }
+    if (!skip) {
+      if constexpr (DKV) { if (masked) body_dkv(BoolTag<true>{}, th0, th1); else body_dkv(BoolTag<false>{}, th0, th1); }
+      else { if (masked) body_dq(BoolTag<true>{}, th0, th1); else body_dq(BoolTag<false>{}, th0, th1); }
+    }
+    // the next tile lives in the other buffer
+    const int flip = (it & 1) ? -B2_BUF : B2_BUF;
+    rowa[0] += flip; rowa[1] += flip;
+#pragma unroll
+    for (int hc = 0; hc < 4; ++hc) tra[hc] += flip;
+    lda += flip;
+    if (more) lwrite((it + 1) & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: lane (owner row l31 of strip os, half hi) holds features dt*32 + hi*16 + r of strip dt
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int os = 0; os < 2; ++os) {
+    const int row = ow0 + os * 32 + l31;
+    if (row >= S) continue;
+    if constexpr (DKV) {
+      bf16_t* dk = p.dK + (tok0 + row) * p.lddk + ho * 128 + hi * 16;
+      bf16_t* dv = p.dV + (tok0 + row) * p.lddv + ho * 128 + hi * 16;
+      if (os == 0) {
+        store_strip<0>(dk, p.scale); store_strip<1>(dk + 32, p.scale); store_strip<2>(dk + 64, p.scale); store_strip<3>(dk + 96, p.scale);
+        store_strip<8>(dv, 1.f); store_strip<9>(dv + 32, 1.f); store_strip<10>(dv + 64, 1.f); store_strip<11>(dv + 96, 1.f);
+      } else {
+        store_strip<4>(dk, p.scale); store_strip<5>(dk + 32, p.scale); store_strip<6>(dk + 64, p.scale); store_strip<7>(dk + 96, p.scale);
+        store_strip<12>(dv, 1.f); store_strip<13>(dv + 32, 1.f); store_strip<14>(dv + 64, 1.f); store_strip<15>(dv + 96, 1.f);
+      }
+    } else {
+      bf16_t* dq = p.dQ + (tok0 + row) * p.lddq + ho * 128 + hi * 16;
+      if (os == 0) { store_strip<0>(dq, p.scale); store_strip<1>(dq + 32, p.scale); store_strip<2>(dq + 64, p.scale); store_strip<3>(dq + 96, p.scale); }
+      else { store_strip<4>(dq, p.scale); store_strip<5>(dq + 32, p.scale); store_strip<6>(dq + 64, p.scale); store_strip<7>(dq + 96, p.scale); }
+    }
+  }
+}
+
+// Causal work per owner block is linear in its index (dQ: grows, dK/dV: shrinks): every workgroup takes a pair of blocks
+// from opposite ends, so all workgroups carry the same number of tiles.
+template <bool DKV, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (CAUSAL) {
+    const int nb = (p.S + 255) / 256, x = blockIdx.x;
+    const int npass = (2 * x + 1 < nb) ? 2 : 1;
+#pragma nounroll
+    for (int pass = 0; pass < npass; ++pass) {
+      const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
+      bwd2_block<DKV, true>(p, smem, pass ? small : big, blockIdx.y, blockIdx.z);
+      __syncthreads();
+    }
+  } else {
+    bwd2_block<DKV, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  }
+}
+
+void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    attr = true;
+  }
+  const int nb = (p.S + 255) / 256, nkv = p.nh / p.group;
+  const dim3 gq(causal ? (nb + 1) / 2 : nb, p.nh, p.B), gk(causal ? (nb + 1) / 2 : nb, nkv, p.B);
+  if (causal) {
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p);
+  } else {
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p);
+  }
+}

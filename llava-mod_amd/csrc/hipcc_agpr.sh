@@ -14,8 +14,9 @@ tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
 FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-spill-vgpr-to-agpr=0 $*"
 $HIPCC $FLAGS --cuda-device-only -emit-llvm -S -o "$tmp/dev.ll" "$src" 2> >(grep -v 'hip-link' >&2 || true)
-grep -q '"amdgpu-waves-per-eu"="2"' "$tmp/dev.ll" || { echo "hipcc_agpr.sh: no kernel with __launch_bounds__(512, 2) found in $src" >&2; exit 1; }
-sed -i "s/\"amdgpu-waves-per-eu\"=\"2\"/\"amdgpu-waves-per-eu\"=\"2\" \"amdgpu-agpr-alloc\"=\"$agprs\"/" "$tmp/dev.ll"
+WPE=${WPE:-2}        # waves per SIMD the kernels' __launch_bounds__ ask for: (512, 2) -> 2, (256, 1) -> 1
+grep -q "\"amdgpu-waves-per-eu\"=\"$WPE\"" "$tmp/dev.ll" || { echo "hipcc_agpr.sh: no kernel with amdgpu-waves-per-eu=$WPE found in $src" >&2; exit 1; }
+sed -i "s/\"amdgpu-waves-per-eu\"=\"$WPE\"/\"amdgpu-waves-per-eu\"=\"$WPE\" \"amdgpu-agpr-alloc\"=\"$agprs\"/" "$tmp/dev.ll"
 $LLVM/clang -x ir -target amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -fPIC -mllvm -amdgpu-spill-vgpr-to-agpr=0 -c -o "$tmp/dev.o" "$tmp/dev.ll"
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o "$tmp/dev.out" "$tmp/dev.o"
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--$ARCH \

@@ -36,12 +36,18 @@ def run(B, S, nh, nkv, hd, causal, bwd, ragged=False):
         f = lambda: K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
                                dqkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, sc, causal, sl)
         t = timeit(f)
-        print(json.dumps({"kernel": "attn_bwd", "B": B, "S": S, "nh": nh, "hd": hd, "causal": causal, "ms": round(t * 1e3, 4),
+        print(json.dumps({"kernel": "attn_bwd", "ver": os.environ.get("LMOD_ATTN_BWD", "2"), "B": B, "S": S, "nh": nh, "hd": hd, "causal": causal, "ms": round(t * 1e3, 4),
                           "tflops_algo(2.5x fwd)": round(2.5 * fl / t / 1e12, 1)}), flush=True)
 
 
 if __name__ == "__main__":
     bwd = "--bwd" in sys.argv
+    if "--bwd-only" in sys.argv:                      # the backward at the step's shapes (LMOD_ATTN_BWD=1: generic kernels)
+        run(16, 2048, 16, 16, 128, True, True)
+        run(8, 2048, 16, 16, 128, False, True)
+        run(4, 8192, 16, 16, 128, True, True)
+        run(16, 2048, 16, 16, 128, True, True, ragged=True)
+        sys.exit(0)
     run(8, 2048, 16, 16, 128, True, bwd)
     run(16, 2048, 16, 16, 128, True, False)
     run(16, 2048, 32, 32, 128, True, False)
