@@ -36,6 +36,9 @@
 #define B2_LDS (B2_YIMG + 2 * B2_BUF)
 #define B2_PIN(x) asm volatile("" : "+v"(x))
 #define B2_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef B2_ABL
+#define B2_ABL 0                           // timing ablations, a bit mask (WRONG RESULTS): 1 no barrier, 2 no global->LDS staging in
+#endif                                     //   the loop, 4 no exp2 / dS VALU work, 8 no operand reads from LDS
 #ifndef B2_DEPTH
 #define B2_DEPTH 2                         // operand fragments are read from LDS this many steps ahead
 #endif
@@ -64,6 +67,8 @@ __device__ __forceinline__ void store_strip(bf16_t* dst, const float mul) {   //
   *(u32x4*)(dst + 8) = w1;
 }
 template <int I> using IC = std::integral_constant<int, I>;
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // MFMA result -> first VALU read.  hipcc does not see inside the asm MFMAs, so (a) it inserts no wait states and (b) it is free
 // to hoist the VALU consumers above them.  The pad is an asm statement that "modifies" the accumulators: every consumer is
 // data-dependent on it and it is itself ordered after the MFMAs (all asm volatile).  It is placed after the MFMAs of the step
@@ -115,19 +120,16 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   // ---- owner image Y: rows o0 .. o0+255 (zeros past the end of the sequence) -> LDS, 272-byte rows
   {
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yo, 0, (int)(((long long)(S - 1) * ldyo + 128) * 2), 0x00020000);
+    u32x4 v[16];                                                 // all 16 loads in flight (the main loop's registers are not live yet)
 #pragma unroll
-    for (int bt = 0; bt < 4; ++bt) {
-      u32x4 v[4];
+    for (int i = 0; i < 16; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (uint32_t)((o0 + row) * ldyo + ch * 8) * 2u, 0, 0));
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * (bt * 4 + i), row = id >> 4, ch = id & 15;
-        v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (uint32_t)((o0 + row) * ldyo + ch * 8) * 2u, 0, 0));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * (bt * 4 + i), row = id >> 4, ch = id & 15;
-        *(u32x4*)(smem + row * B2_YPITCH + ch * 16) = v[i];
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      *(u32x4*)(smem + row * B2_YPITCH + ch * 16) = v[i];
     }
   }
   acc_zero_all();
@@ -147,21 +149,24 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   const int wa0 = B2_YIMG + srow * B2_PITCH + ((sch ^ ((srow >> 3) & 3)) << 4);
   const int wa1 = B2_YIMG + (srow + 16) * B2_PITCH + ((sch ^ (((srow + 16) >> 3) & 3)) << 4);
   u32x4 xr0, xr1, yr0, yr1;
-  float ldr = 0.f;
-  auto gload = [&](const int it) {
-    const int hh = it / per_head, j = first + it - hh * per_head;
+  uint32_t lsr = 0, dlr = 0;                                    // dK/dV kernel: one lse / delta value of the staged tile
+  const long long ld0 = ((long long)b * p.nh + (DKV ? ho * p.group : ho)) * p.S;
+  const __amdgpu_buffer_rsrc_t rlse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.LSE + ld0), 0, gsz * p.S * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdel = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Delta + ld0), 0, gsz * p.S * 4, 0x00020000);
+  int ghh = 0, gj = first;                                      // (head, tile) of the next gload: consecutive calls
+  auto gload = [&](const int) {
+    const int hh = ghh, j = gj;
+    if (++gj == nt) { gj = first; ++ghh; }
     const uint32_t ax = (uint32_t)(j * 32 * ldxs + hh * 128) * 2u, ay = (uint32_t)(j * 32 * ldys + hh * 128) * 2u;
     xr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg0 + ax, 0, 0));
     xr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg1 + ax, 0, 0));
     yr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg0 + ay, 0, 0));
     yr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg1 + ay, 0, 0));
-    if constexpr (DKV) {
-      if (tid < 64) {
-        const int t = j * 32 + (tid & 31);
-        const long long si = ((long long)b * p.nh + ho * p.group + hh) * p.S + min(t, S - 1);
-        const float v = (tid < 32) ? p.LSE[si] * 1.4426950408889634f : p.Delta[si];
-        ldr = (t < S) ? v : 0.f;
-      }
+    if constexpr (DKV) {        // lse / delta of the tile's 32 rows: lanes 0-31 of every wave fetch them (no branch, no arithmetic
+      const int t = j * 32 + l31;      // on the loaded value here: either would make hipcc wait for the loads at once)
+      const uint32_t o = (hi == 0 && t < S) ? (uint32_t)((hh * p.S + t) * 4) : 0xffffffffu;
+      lsr = __builtin_amdgcn_raw_buffer_load_b32(rlse, o, 0, 0);
+      dlr = __builtin_amdgcn_raw_buffer_load_b32(rdel, o, 0, 0);
     }
   };
   auto lwrite = [&](const int buf) {
@@ -170,7 +175,12 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     *(u32x4*)(bb + wa1) = xr1;
     *(u32x4*)(bb + B2_TILE + wa0) = yr0;
     *(u32x4*)(bb + B2_TILE + wa1) = yr1;
-    if constexpr (DKV) { if (tid < 64) *(float*)(bb + B2_YIMG + B2_LD + tid * 4) = ldr; }
+    if constexpr (DKV) {
+      if (tid < 32) {
+        *(float*)(bb + B2_YIMG + B2_LD + tid * 4) = __uint_as_float(lsr) * 1.4426950408889634f;
+        *(float*)(bb + B2_YIMG + B2_LD + 128 + tid * 4) = __uint_as_float(dlr);
+      }
+    }
   };
 
   // ---- operand read addresses (bytes from smem; immediates carry feature group, row group and tensor)
@@ -186,61 +196,58 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   int lda = B2_YIMG + B2_LD + hi * 16;
   const int ya = (wave * 64 + l31) * B2_YPITCH + hi * 16;
 
-  auto rd_xs = [&](const int ks) { return *(const bf16x8*)(smem + rowa[ks & 1] + (ks >> 1) * 64); };
-  auto rd_ys = [&](const int ks) { return *(const bf16x8*)(smem + rowa[ks & 1] + B2_TILE + (ks >> 1) * 64); };
-  auto rd_y = [&](const int os, const int ks) { return *(const bf16x8*)(smem + ya + os * 32 * B2_YPITCH + ks * 32); };
+  auto rd_xs = [&](const int ks) { if (B2_ABL & 8) return xf[0][ks]; return *(const bf16x8*)(smem + rowa[ks & 1] + (ks >> 1) * 64); };
+  auto rd_ys = [&](const int ks) { if (B2_ABL & 8) return xf[1][ks]; return *(const bf16x8*)(smem + rowa[ks & 1] + B2_TILE + (ks >> 1) * 64); };
+  auto rd_y = [&](const int os, const int ks) { if (B2_ABL & 8) return xf[os][ks]; return *(const bf16x8*)(smem + ya + os * 32 * B2_YPITCH + ks * 32); };
   auto rd_tr = [&](const int tensor, const int tk, const int dt) {
+    if (B2_ABL & 8) return xf[tensor][tk * 4 + dt];
     return tr2(smem + tra[(2 * tk) & 3] + tensor * B2_TILE + (16 * tk) * B2_PITCH + dt * 64,
                smem + tra[(2 * tk + 1) & 3] + tensor * B2_TILE + (16 * tk + 8) * B2_PITCH + dt * 64);
   };
 
   f32x16 s[2], dp[2];
   uint32_t pP[2][8], pS[2][8];         // bf16-packed P and dS: [owner strip][4 * reduction step of 16 streamed rows + dword]
+  f32x4 l4c = {0.f, 0.f, 0.f, 0.f}, d4c = {0.f, 0.f, 0.f, 0.f};   // dK/dV kernel: lse / delta of the 4 streamed rows being processed
 
-  // p = exp2(s c - lse) of rows 4*G4 .. +3 of strip OS (masked entries -> 0); dK/dV kernel: packed into pP
-  auto exp_grp = [&](auto masked_t, auto os_t, auto g4_t, const int thr) {
+  // VALU work comes in PIECES of two elements so that one piece fits behind one MFMA.
+  // exp piece N (0..15): rows 4*G4 + 2*H, +1 of strip OS, with G4 = N >> 2, OS = (N >> 1) & 1, H = N & 1 (dK/dV kernel order:
+  // both strips of a row group share the lse / delta values read from LDS); p = exp2(s c - lse), masked entries -> 0
+  auto exp_piece = [&](auto masked_t, auto os_t, auto g4_t, auto h_t, const int thr) {
     constexpr bool MASKED = decltype(masked_t)::value;
-    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value;
-    f32x4 l4;
-    if constexpr (DKV) l4 = *(const f32x4*)(smem + lda + G4 * 32);
-    else l4 = (f32x4){olse[OS], olse[OS], olse[OS], olse[OS]};
+    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
+    if (B2_ABL & 4) { if (DKV) pP[OS][2 * G4 + H] = 0x3c003c00u; return; }
+    if constexpr (DKV) { if (OS == 0 && H == 0) l4c = *(const f32x4*)(smem + lda + G4 * 32); }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 2 * H; e < 2 * H + 2; ++e) {
       const int r = 4 * G4 + e, base = (r & 3) + 8 * (r >> 2);
-      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[OS][r], c, -l4[e]));
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[OS][r], c, DKV ? -l4c[e] : -olse[OS]));
       if constexpr (MASKED) { if (DKV ? (base < thr) : (base > thr)) pv = 0.f; }
       s[OS][r] = pv;
     }
     if constexpr (DKV) {
-      pP[OS][2 * G4] = pack2bf(s[OS][4 * G4], s[OS][4 * G4 + 1]);
-      pP[OS][2 * G4 + 1] = pack2bf(s[OS][4 * G4 + 2], s[OS][4 * G4 + 3]);
-      B2_PIN(pP[OS][2 * G4]); B2_PIN(pP[OS][2 * G4 + 1]);
+      pP[OS][2 * G4 + H] = pack2bf(s[OS][4 * G4 + 2 * H], s[OS][4 * G4 + 2 * H + 1]);
+      B2_PIN(pP[OS][2 * G4 + H]);
     } else {
-      B2_PIN(s[OS]);
+      B2_PIN(s[OS][4 * G4 + 2 * H]);
     }
   };
-  // dS = p (dp - delta) of the same rows, packed into pS.  SUB: delta still to be subtracted
-  auto ds_grp = [&](auto sub_t, auto os_t, auto g4_t) {
+  // dS piece: dS = p (dp - delta) of the same two rows, packed.  SUB: delta still to be subtracted (dK/dV kernel)
+  auto ds_piece = [&](auto sub_t, auto os_t, auto g4_t, auto h_t) {
     constexpr bool SUB = decltype(sub_t)::value;
-    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value;
-    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (SUB) {
-      if constexpr (DKV) d4 = *(const f32x4*)(smem + lda + 128 + G4 * 32);
-      else d4 = (f32x4){odl[OS], odl[OS], odl[OS], odl[OS]};
-    }
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = 4 * G4 + e;
-      v[e] = s[OS][r] * (SUB ? dp[OS][r] - d4[e] : dp[OS][r]);
-    }
-    pS[OS][2 * G4] = pack2bf(v[0], v[1]);
-    pS[OS][2 * G4 + 1] = pack2bf(v[2], v[3]);
-    B2_PIN(pS[OS][2 * G4]); B2_PIN(pS[OS][2 * G4 + 1]);
+    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
+    if (B2_ABL & 4) { pS[OS][2 * G4 + H] = 0x3c003c00u; return; }
+    if constexpr (SUB && DKV) { if (OS == 0 && H == 0) d4c = *(const f32x4*)(smem + lda + 128 + G4 * 32); }
+    const int r = 4 * G4 + 2 * H;
+    const float v0 = s[OS][r] * (SUB ? dp[OS][r] - d4c[2 * H] : dp[OS][r]);
+    const float v1 = s[OS][r + 1] * (SUB ? dp[OS][r + 1] - d4c[2 * H + 1] : dp[OS][r + 1]);
+    pS[OS][2 * G4 + H] = pack2bf(v0, v1);
+    B2_PIN(pS[OS][2 * G4 + H]);
   };
   auto opnd = [](const uint32_t (&w)[8], const int tk) {
     return __builtin_bit_cast(bf16x8, (u32x4){w[4 * tk], w[4 * tk + 1], w[4 * tk + 2], w[4 * tk + 3]});
   };
+  using T = BoolTag<true>;
+  using F = BoolTag<false>;
 
   // ================================================================================ dK/dV tile body
   auto body_dkv = [&](auto masked_t, const int lo0, const int lo1) {
@@ -249,88 +256,76 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      static_for<8>([&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value;
         if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
-        if (ks == 0) { sd_mfma<true>(s[0], a, xf[0][0]); sd_mfma<true>(s[1], a, xf[1][0]); }
-        else { sd_mfma<false>(s[0], a, xf[0][ks]); sd_mfma<false>(s[1], a, xf[1][ks]); }
+        sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
+        sd_mfma<ks == 0>(s[1], a, xf[1][ks]);
         B2_SB();
-      }
+      });
     }
-    // ---- dP = Ys Y^T  ||  P = exp2(S c - lse), packed
+    // ---- dP = Ys Y^T  ||  P = exp2(S c - lse), packed: one piece behind every MFMA
     {
       bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); b0[st] = rd_y(0, st); b1[st] = rd_y(1, st); }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
+      static_for<8>([&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
         if (nx < 8) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
-        if (ks == 0) { sd_mfma<true>(dp[0], af[cu], b0[cu]); sd_mfma<true>(dp[1], af[cu], b1[cu]); }
-        else { sd_mfma<false>(dp[0], af[cu], b0[cu]); sd_mfma<false>(dp[1], af[cu], b1[cu]); }
+        sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
         if (ks == 0) hazard_pad(s[0], s[1]);
-        if (ks == 0) exp_grp(masked_t, IC<0>{}, IC<0>{}, lo0);
-        if (ks == 1) exp_grp(masked_t, IC<0>{}, IC<1>{}, lo0);
-        if (ks == 2) exp_grp(masked_t, IC<1>{}, IC<0>{}, lo1);
-        if (ks == 3) exp_grp(masked_t, IC<1>{}, IC<1>{}, lo1);
-        if (ks == 4) exp_grp(masked_t, IC<0>{}, IC<2>{}, lo0);
-        if (ks == 5) exp_grp(masked_t, IC<0>{}, IC<3>{}, lo0);
-        if (ks == 6) exp_grp(masked_t, IC<1>{}, IC<2>{}, lo1);
-        if (ks == 7) exp_grp(masked_t, IC<1>{}, IC<3>{}, lo1);
+        exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<0>{}, (ks & 1) ? lo1 : lo0);
         B2_SB();
-      }
+        sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
+        exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<1>{}, (ks & 1) ? lo1 : lo0);
+        B2_SB();
+      });
     }
     // ---- dV^T += Ys^T P  ||  dS = P (dP - delta), packed
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(1, st >> 2, st & 3);
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+      static_for<8>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
         if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx >> 2, nx & 3);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
-        if (dt == 0) { acc_mfma<8>(a, opnd(pP[0], tk)); acc_mfma<12>(a, opnd(pP[1], tk)); }
-        if (dt == 1) { acc_mfma<9>(a, opnd(pP[0], tk)); acc_mfma<13>(a, opnd(pP[1], tk)); }
-        if (dt == 2) { acc_mfma<10>(a, opnd(pP[0], tk)); acc_mfma<14>(a, opnd(pP[1], tk)); }
-        if (dt == 3) { acc_mfma<11>(a, opnd(pP[0], tk)); acc_mfma<15>(a, opnd(pP[1], tk)); }
+        acc_mfma<8 + dt>(a, opnd(pP[0], tk));
         if (st == 0) hazard_pad(dp[0], dp[1]);
-        using T = BoolTag<true>;
-        if (st == 0) ds_grp(T{}, IC<0>{}, IC<0>{});
-        if (st == 1) ds_grp(T{}, IC<0>{}, IC<1>{});
-        if (st == 2) ds_grp(T{}, IC<1>{}, IC<0>{});
-        if (st == 3) ds_grp(T{}, IC<1>{}, IC<1>{});
-        if (st == 4) ds_grp(T{}, IC<0>{}, IC<2>{});
-        if (st == 5) ds_grp(T{}, IC<0>{}, IC<3>{});
-        if (st == 6) ds_grp(T{}, IC<1>{}, IC<2>{});
-        if (st == 7) ds_grp(T{}, IC<1>{}, IC<3>{});
+        ds_piece(T{}, IC<(st & 1)>{}, IC<(st / 2)>{}, IC<0>{});
         B2_SB();
-      }
+        acc_mfma<12 + dt>(a, opnd(pP[1], tk));
+        ds_piece(T{}, IC<(st & 1)>{}, IC<(st / 2)>{}, IC<1>{});
+        B2_SB();
+      });
     }
     // ---- dK^T += Xs^T dS
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
+      static_for<8>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
         if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
-        if (dt == 0) { acc_mfma<0>(a, opnd(pS[0], tk)); acc_mfma<4>(a, opnd(pS[1], tk)); }
-        if (dt == 1) { acc_mfma<1>(a, opnd(pS[0], tk)); acc_mfma<5>(a, opnd(pS[1], tk)); }
-        if (dt == 2) { acc_mfma<2>(a, opnd(pS[0], tk)); acc_mfma<6>(a, opnd(pS[1], tk)); }
-        if (dt == 3) { acc_mfma<3>(a, opnd(pS[0], tk)); acc_mfma<7>(a, opnd(pS[1], tk)); }
+        acc_mfma<dt>(a, opnd(pS[0], tk));
+        acc_mfma<4 + dt>(a, opnd(pS[1], tk));
         B2_SB();
-      }
+      });
     }
   };
 
   // ================================================================================ dQ tile body
   auto body_dq = [&](auto masked_t, const int up0, const int up1) {
-    using T = BoolTag<true>;
-    using F = BoolTag<false>;
+    auto exp_grp = [&](auto m_t, auto os_t, auto g4_t, const int thr) {
+      exp_piece(m_t, os_t, g4_t, IC<0>{}, thr);
+      exp_piece(m_t, os_t, g4_t, IC<1>{}, thr);
+    };
+    auto ds_grp = [&](auto sub_t, auto os_t, auto g4_t) {
+      ds_piece(sub_t, os_t, g4_t, IC<0>{});
+      ds_piece(sub_t, os_t, g4_t, IC<1>{});
+    };
     // ---- dP = Ys Y^T   (Ys = V rows, Y = dO image)
     {
       bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
@@ -428,14 +423,21 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     }
   };
 
-  // ---- prologue
+  // ---- prologue: tile 0 in LDS, tile 1 in flight towards the staging registers
   if (total > 0) { gload(0); lwrite(0); }
+  if (total > 1 && !(B2_ABL & 2)) gload(1);
   __syncthreads();
 
+  // Staging (one register set): the registers hold tile it+1, loaded during iteration it-1.  They are written to LDS right
+  // AFTER the barrier that ended iteration it-1 (its readers of that buffer are done), the loads of tile it+2 are re-issued
+  // into the same registers at once, and both overlap the MFMAs of tile it; nothing but the barrier follows the last MFMA.
+  int hh = 0, j = first;                                        // (head of the group, tile) of iteration `it`
   for (int it = 0; it < total; ++it) {
-    const int hh = it / per_head, j = first + it - hh * per_head, t0 = j * 32;
-    const bool more = it + 1 < total;
-    if (more) gload(it + 1);
+    const int t0 = j * 32;
+    if (!(B2_ABL & 2)) {
+      if (it + 1 < total) lwrite((it + 1) & 1);
+      if (it + 2 < total) gload(it + 2);
+    }
     bool skip, masked;
     int th0, th1;
     if constexpr (DKV) {
@@ -463,9 +465,9 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 #pragma unroll
     for (int hc = 0; hc < 4; ++hc) tra[hc] += flip;
     lda += flip;
-    if (more) lwrite((it + 1) & 1);
+    if (++j == nt) { j = first; ++hh; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(B2_ABL & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
 
@@ -496,19 +498,23 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 // Causal work per owner block is linear in its index (dQ: grows, dK/dV: shrinks): every workgroup takes a pair of blocks
 // from opposite ends, so all workgroups carry the same number of tiles.
 template <bool DKV, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p, int gx, int gy, int gz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // 1-D grid, XCD-aware: the workgroups of one (batch, head) — which stream the same Q / dO (K / V) rows — are adjacent logical
+  // ids and every XCD takes one contiguous chunk of logical ids, so they share one private L2.
+  const int lid = xcd_remap(blockIdx.x, gx * gy * gz);
+  const int x = lid % gx, y = (lid / gx) % gy, z = lid / (gx * gy);
   if constexpr (CAUSAL) {
-    const int nb = (p.S + 255) / 256, x = blockIdx.x;
+    const int nb = (p.S + 255) / 256;
     const int npass = (2 * x + 1 < nb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true>(p, smem, pass ? small : big, blockIdx.y, blockIdx.z);
+      bwd2_block<DKV, true>(p, smem, pass ? small : big, y, z);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    bwd2_block<DKV, false>(p, smem, x, y, z);
   }
 }
 
@@ -521,13 +527,13 @@ void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
     attr = true;
   }
-  const int nb = (p.S + 255) / 256, nkv = p.nh / p.group;
-  const dim3 gq(causal ? (nb + 1) / 2 : nb, p.nh, p.B), gk(causal ? (nb + 1) / 2 : nb, nkv, p.B);
+  const int nb = (p.S + 255) / 256, nkv = p.nh / p.group, gx = causal ? (nb + 1) / 2 : nb;
+  const dim3 gq(gx * p.nh * p.B), gk(gx * nkv * p.B);
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p, gx, p.nh, p.B);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p, gx, nkv, p.B);
   } else {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p, gx, p.nh, p.B);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p, gx, nkv, p.B);
   }
 }

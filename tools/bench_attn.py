@@ -42,6 +42,10 @@ def run(B, S, nh, nkv, hd, causal, bwd, ragged=False):
 
 if __name__ == "__main__":
     bwd = "--bwd" in sys.argv
+    if "--bwd-one" in sys.argv:
+        run(16, 2048, 16, 16, 128, True, True)
+        run(8, 2048, 16, 16, 128, False, True)
+        sys.exit(0)
     if "--bwd-only" in sys.argv:                      # the backward at the step's shapes (LMOD_ATTN_BWD=1: generic kernels)
         run(16, 2048, 16, 16, 128, True, True)
         run(8, 2048, 16, 16, 128, False, True)
