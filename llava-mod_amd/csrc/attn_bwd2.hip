@@ -207,39 +207,46 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 
   f32x16 s[2], dp[2];
   uint32_t pP[2][8], pS[2][8];         // bf16-packed P and dS: [owner strip][4 * reduction step of 16 streamed rows + dword]
-  f32x4 l4c = {0.f, 0.f, 0.f, 0.f}, d4c = {0.f, 0.f, 0.f, 0.f};   // dK/dV kernel: lse / delta of the 4 streamed rows being processed
+  f32x4 l4c[2], d4c[2];                // dK/dV kernel: lse / delta of the 4 streamed rows of row group G4, in slot G4 & 1;
+                                       // read from LDS one row group AHEAD of their use (a read placed at its use costs
+                                       // an LDS round trip per group with nothing else for this one wave to issue)
+  auto ld_l4 = [&](const int g4) { if constexpr (DKV) l4c[g4 & 1] = *(const f32x4*)(smem + lda + g4 * 32); };
+  auto ld_d4 = [&](const int g4) { if constexpr (DKV) d4c[g4 & 1] = *(const f32x4*)(smem + lda + 128 + g4 * 32); };
 
   // VALU work comes in PIECES of two elements so that one piece fits behind one MFMA.
   // exp piece N (0..15): rows 4*G4 + 2*H, +1 of strip OS, with G4 = N >> 2, OS = (N >> 1) & 1, H = N & 1 (dK/dV kernel order:
-  // both strips of a row group share the lse / delta values read from LDS); p = exp2(s c - lse), masked entries -> 0
+  // both strips of a row group share the lse / delta values read from LDS); p = exp2(s c - lse), masked entries -> 0.
+  // The bf16 packing of a piece is issued with the NEXT piece (v_exp -> consumer needs a wait state: hipcc pads with s_nop
+  // unless an independent instruction sits between them).
   auto exp_piece = [&](auto masked_t, auto os_t, auto g4_t, auto h_t, const int thr) {
     constexpr bool MASKED = decltype(masked_t)::value;
     constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
-    if (B2_ABL & 4) { if (DKV) pP[OS][2 * G4 + H] = 0x3c003c00u; return; }
-    if constexpr (DKV) { if (OS == 0 && H == 0) l4c = *(const f32x4*)(smem + lda + G4 * 32); }
+    if (B2_ABL & 4) return;
+    if constexpr (DKV) { if (OS == 0 && H == 0 && G4 < 3) ld_l4(G4 + 1); }
 #pragma unroll
     for (int e = 2 * H; e < 2 * H + 2; ++e) {
       const int r = 4 * G4 + e, base = (r & 3) + 8 * (r >> 2);
-      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[OS][r], c, DKV ? -l4c[e] : -olse[OS]));
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[OS][r], c, DKV ? -l4c[G4 & 1][e] : -olse[OS]));
       if constexpr (MASKED) { if (DKV ? (base < thr) : (base > thr)) pv = 0.f; }
       s[OS][r] = pv;
     }
-    if constexpr (DKV) {
-      pP[OS][2 * G4 + H] = pack2bf(s[OS][4 * G4 + 2 * H], s[OS][4 * G4 + 2 * H + 1]);
-      B2_PIN(pP[OS][2 * G4 + H]);
-    } else {
-      B2_PIN(s[OS][4 * G4 + 2 * H]);
-    }
+    if constexpr (!DKV) B2_PIN(s[OS][4 * G4 + 2 * H]);
+  };
+  auto pack_piece = [&](auto os_t, auto g4_t, auto h_t) {        // dK/dV kernel: P of the piece -> bf16 pair
+    constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
+    if (B2_ABL & 4) { pP[OS][2 * G4 + H] = 0x3c003c00u; return; }
+    pP[OS][2 * G4 + H] = pack2bf(s[OS][4 * G4 + 2 * H], s[OS][4 * G4 + 2 * H + 1]);
+    B2_PIN(pP[OS][2 * G4 + H]);
   };
   // dS piece: dS = p (dp - delta) of the same two rows, packed.  SUB: delta still to be subtracted (dK/dV kernel)
   auto ds_piece = [&](auto sub_t, auto os_t, auto g4_t, auto h_t) {
     constexpr bool SUB = decltype(sub_t)::value;
     constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
     if (B2_ABL & 4) { pS[OS][2 * G4 + H] = 0x3c003c00u; return; }
-    if constexpr (SUB && DKV) { if (OS == 0 && H == 0) d4c = *(const f32x4*)(smem + lda + 128 + G4 * 32); }
+    if constexpr (SUB && DKV) { if (OS == 0 && H == 0 && G4 < 3) ld_d4(G4 + 1); }
     const int r = 4 * G4 + 2 * H;
-    const float v0 = s[OS][r] * (SUB ? dp[OS][r] - d4c[2 * H] : dp[OS][r]);
-    const float v1 = s[OS][r + 1] * (SUB ? dp[OS][r + 1] - d4c[2 * H + 1] : dp[OS][r + 1]);
+    const float v0 = s[OS][r] * (SUB ? dp[OS][r] - d4c[G4 & 1][2 * H] : dp[OS][r]);
+    const float v1 = s[OS][r + 1] * (SUB ? dp[OS][r + 1] - d4c[G4 & 1][2 * H + 1] : dp[OS][r + 1]);
     pS[OS][2 * G4 + H] = pack2bf(v0, v1);
     B2_PIN(pS[OS][2 * G4 + H]);
   };
@@ -262,6 +269,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
         sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
         sd_mfma<ks == 0>(s[1], a, xf[1][ks]);
+        if (ks == 5) ld_l4(0);
         B2_SB();
       });
     }
@@ -276,9 +284,12 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
         if (ks == 0) hazard_pad(s[0], s[1]);
         exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<0>{}, (ks & 1) ? lo1 : lo0);
+        if constexpr (ks > 0) pack_piece(IC<((ks - 1) & 1)>{}, IC<((ks - 1) / 2)>{}, IC<1>{});
         B2_SB();
         sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
         exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<1>{}, (ks & 1) ? lo1 : lo0);
+        pack_piece(IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<0>{});
+        if (ks == 6) ld_d4(0);
         B2_SB();
       });
     }
@@ -291,6 +302,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         constexpr int st = decltype(st_t)::value, tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
         if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx >> 2, nx & 3);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
+        if (st == 0) pack_piece(IC<1>{}, IC<3>{}, IC<1>{});          // the last exp piece's pair (feeds tk = 1 only)
         acc_mfma<8 + dt>(a, opnd(pP[0], tk));
         if (st == 0) hazard_pad(dp[0], dp[1]);
         ds_piece(T{}, IC<(st & 1)>{}, IC<(st / 2)>{}, IC<0>{});
