@@ -81,24 +81,25 @@ def test_product_path_never_touches_the_oracle_or_the_reference():
                 assert enclosing.startswith(f"def {allowed}"), (name, i + 1, enclosing)
 
 
-def test_asm_owned_accumulators_are_not_touched_by_the_compiler(tmp_path):
-    """attn_fwd2.hip keeps its O^T accumulators in a[0:63] through inline asm only (see the file header).  Audit the ISA
-    hipcc emits for it: no spills, exactly the 64 accumulator registers the asm names, and no instruction outside an asm
-    statement that references an accumulator register."""
+@pytest.mark.parametrize("src,agprs,wpe,nkern", [("attn_fwd2.hip", 64, 2, 2), ("attn_bwd2.hip", 256, 1, 4)])
+def test_asm_owned_accumulators_are_not_touched_by_the_compiler(tmp_path, src, agprs, wpe, nkern):
+    """attn_fwd2.hip keeps its O^T accumulators in a[0:63], attn_bwd2.hip its dQ / dK / dV accumulators in a[0:255], through
+    inline asm only (see the file headers).  Audit the ISA hipcc emits: no spills, exactly the accumulator registers the asm
+    names, and no instruction outside an asm statement that references an accumulator register."""
     import re
     import shutil
     import subprocess
     csrc = os.path.join(ROOT, "llava-mod_amd", "csrc")
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
-    env = dict(os.environ, KEEP_ISA=str(tmp_path / "fwd2.s"))
+    env = dict(os.environ, KEEP_ISA=str(tmp_path / "k.s"), WPE=str(wpe))
     env["PATH"] = "/opt/rocm/bin:" + env.get("PATH", "")
-    subprocess.run([os.path.join(csrc, "hipcc_agpr.sh"), os.path.join(csrc, "attn_fwd2.hip"), str(tmp_path / "fwd2.o"), "64"],
+    subprocess.run([os.path.join(csrc, "hipcc_agpr.sh"), os.path.join(csrc, src), str(tmp_path / "k.o"), str(agprs)],
                    check=True, env=env)
-    isa = open(tmp_path / "fwd2.s").read()
-    assert re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa) == ["0", "0"]
-    assert re.findall(r"\.private_segment_fixed_size:\s+(\d+)", isa) == ["0", "0"]
-    assert re.findall(r"\.agpr_count:\s+(\d+)", isa) == ["64", "64"]
+    isa = open(tmp_path / "k.s").read()
+    assert re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa) == ["0"] * nkern
+    assert re.findall(r"\.private_segment_fixed_size:\s+(\d+)", isa) == ["0"] * nkern
+    assert re.findall(r"\.agpr_count:\s+(\d+)", isa) == [str(agprs)] * nkern
     in_asm, bad = False, []
     for line in isa.split("\n"):
         if "#ASMSTART" in line:
