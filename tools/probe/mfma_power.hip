@@ -43,7 +43,8 @@ __global__ __launch_bounds__(512, 2) void spin(const bf16x8* __restrict__ in, fl
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 3;      // 2 x ~11 ms launches per rep
   bf16x8* in; float* out;
   hipMalloc(&in, 65536 * 16); hipMalloc(&out, 2048 * 512 * 4);
   uint16_t* h = (uint16_t*)malloc(65536 * 16);
@@ -52,7 +53,7 @@ int main() {
   hipMemcpy(in, h, 65536 * 16, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000, blocks = 512;
-  for (int rep = 0; rep < 3; ++rep)
+  for (int rep = 0; rep < reps; ++rep)
     for (int shape : {16, 32}) {
       if (shape == 16) hipLaunchKernelGGL(spin<16>, dim3(blocks), dim3(512), 0, 0, in, out, 100);
       else hipLaunchKernelGGL(spin<32>, dim3(blocks), dim3(512), 0, 0, in, out, 100);
