@@ -3,13 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One "step" = one full mimic-distillation optimizer step on one micro-batch per GPU (config 2 of
-BASELINE.json: CLIP-ViT-L/14-336 + Qwen-1.8B-MoE top-2/4-expert student, Qwen-7B dense teacher, bf16):
-frozen teacher forward + student forward/backward + KD/LM/aux losses (the d2s recipe `kd_lm` +
-moe_loss) + RCCL gradient all-reduce over the DP group + fused AdamW.  Synthetic data of the real
-shape (336x336 image -> 576 patches + 1472 text tokens = 2048 context, 512 response tokens), random
-init of the real architecture.  value = image-text samples / s over ALL ranks (weak scaling: fixed
-micro-batch per GPU).  Prints ONE JSON line on rank 0.
+One "step" = one full mimic-distillation OPTIMIZER step (config 2 of BASELINE.json: CLIP-ViT-L/14-336 +
+Qwen-1.8B-MoE top-2/4-expert student, Qwen-7B dense teacher, bf16): `--grad-accum` (default 2) micro-batches
+of `--micro-batch` (default 16) samples per GPU — config 3's 8 x 32 = 256 global batch at N=8 — each a frozen
+teacher forward + student forward/backward + KD/LM/aux losses (the d2s recipe `kd_lm` + moe_loss), then ONE
+gradient exchange over the DP group (RCCL reduce-scatter, ZeRO-2 style sharded optimizer state; all-reduce with
+`--no-zero2`), global-norm clipping at 1.0 and the fused AdamW (+ in-place all-gather of the bf16 weights).
+Synthetic data of the real shape (336x336 image -> 576 patches + 1472 text tokens = 2048 context, 512 response
+tokens; `--ragged`: text lengths U[600,1473]), random init of the real architecture.  value = image-text
+samples / s over ALL ranks (weak scaling: fixed work per GPU).  Prints ONE JSON line on rank 0 with `roofline`
+(dominant kernel, timed live with HIP events) and `cpu_baseline` (the fp32 oracle's full-depth step on the host cores,
+rank 0 at N=1, with the GPU-vs-oracle loss difference).
 """
 import argparse
 import json
@@ -183,8 +187,8 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto"):
                   f"(host RAM {mem:.0f} GB): {tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s")
         value = 1.0 / t_cpu
     else:
-        sample = (f"oracle fp32 torch-CPU mimic step, B=1 S=2048, config-2 widths, DEPTH-REDUCED (host RAM {mem:.0f} GB < 96 GB "
-                  f"or --cpu-baseline sample) to teacher {t_l}/32, student {s_l}/24, ViT {vit_l}/23 layers, full-vocab heads: "
+        sample = (f"oracle fp32 torch-CPU mimic step, B=1 S=2048, config-2 widths, DEPTH-REDUCED ("
+                  f"{'--cpu-baseline sample' if mode == 'sample' else f'host RAM {mem:.0f} GB < 96 GB'}) to teacher {t_l}/32, student {s_l}/24, ViT {vit_l}/23 layers, full-vocab heads: "
                   f"{tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s; scaled to the 52.98 TFLOP full-depth sample")
         value = rate / TFLOP_PER_SAMPLE_LEDGER
     out = {"value": round(value, 5), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
@@ -343,13 +347,14 @@ def main():
         gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
         traffic, traffic_note = None, "no committed PMC pass for this shape"
-        tp = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
-        if os.path.exists(tp):
+        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
+                   if os.path.exists(t)), "")
+        if tp:
             tj = json.load(open(tp))
             if tj["shape"] == [gm, gn, gk]:
                 traffic = round((tj["fetch_bytes_corrected"] + tj["write_bytes"]) / 1e9, 2)
                 traffic_note = (f"GB per launch at the L2/fabric boundary (Infinity-Cache hits included), {tj['source']}; "
-                                f"algorithmic {tj['algorithmic_bytes'] / 1e9:.2f} GB — see profiles/r01_final_pmc.md")
+                                f"algorithmic {tj['algorithmic_bytes'] / 1e9:.2f} GB — see profiles/{os.path.basename(tp).replace('gemm_traffic.json', 'pmc.md')}")
         out = {
             "metric": "distillation samples/sec (336px img + 2k ctx), 2B-MoE student / 7B teacher",
             "value": round(sps, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -3,6 +3,7 @@ usage: python tools/profile_md.py gpurun_out/final profiles/r01_final"""
 import collections, csv, glob, json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+TAG = os.path.basename(dst).replace("_", " ")
 
 
 def stats_md():
@@ -11,11 +12,12 @@ def stats_md():
     line = json.loads(open(f"{src}/bench_line.json").read())
     n_steps = line["steps"] + line["warmup"]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    out = ["# rocprofv3 --kernel-trace --stats of the default bench workload (round 1, final)", "",
+    out = [f"# rocprofv3 --kernel-trace --stats of the default bench workload ({TAG})", "",
            "Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
            "--no-cpu-baseline --no-teacher-prefetch` (teacher pipelining off so that kernel durations do not overlap; the "
            "default bench line with pipelining on is in `*_bench_n1.json`).", "",
-           f"{n_steps} steps (1 warm-up + 3 timed), micro-batch {line['config']['micro_batch_per_gpu']}, config 2.  Sum of kernel "
+           f"{n_steps} optimizer steps (1 warm-up + 3 timed) of {line['config'].get('grad_accum', 1)} micro-batches x "
+           f"{line['config']['micro_batch_per_gpu']} samples, config 2.  Sum of kernel "
            f"time {tot / 1e6:.1f} ms = {tot / 1e6 / n_steps:.1f} ms/step; bench wall clock under the profiler "
            f"{line['ms_per_step']} ms/step ({line['value']} samples/s).  Model construction is inside the trace (torch "
            "`distribution_elementwise` / `copyBuffer` rows).", "",
@@ -31,7 +33,7 @@ def stats_md():
     rl = line["roofline"]
     out += ["", "## Dominant kernel cross-check", "",
             f"`gemm_256_kernel<0>` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
-            f"trace (32 per step inside the teacher + the 12 that bench.py times with HIP events), average {sum(d) / len(d):.1f} us, "
+            f"trace (32 per micro-batch inside the teacher + the ones bench.py times with HIP events), average {sum(d) / len(d):.1f} us, "
             f"min {min(d):.1f}, max {max(d):.1f}.  bench.py's live HIP-event figure in the same run: {rl['launch_ms'] * 1e3:.1f} us "
             f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak)."]
     by = collections.defaultdict(lambda: [0, 0.0])
@@ -62,7 +64,7 @@ def pmc(run):
 
 
 def pmc_md():
-    out = ["# PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only) — round 1, final", "",
+    out = [f"# PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only) — {TAG}", "",
            "Per-dispatch averages.  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles; "
            "`SQ_VALU_MFMA_BUSY_CYCLES` counts cycles summed over the 1024 SIMDs; `GRBM_GUI_ACTIVE` is summed over the 8 XCDs.", ""]
     g = pmc("gemm_sq"); f = pmc("gemm_fetch"); w = pmc("gemm_write")
@@ -88,7 +90,8 @@ def pmc_md():
             "", "| counter | per dispatch |", "|---|---|"]
     out += [f"| {a} | {b:.4g} |" for a, b in sorted(c.items())]
     a = pmc("attn_sq")
-    out += ["", "## attention kernels, B 8, S 2048, 16 heads, hd 128, causal (`python tools/attn_one.py bwd`)", "",
+    out += ["", "## attention kernels, B 16, S 2048, 16 heads, hd 128, causal (`A1_B=16 python tools/attn_one.py bwd`; first launches, "
+            "clock not yet settled: durations are longer than in the micro-benchmarks)", "",
             "| kernel | us | clock GHz | MFMA busy % | LDS active % of CU cycles | LDS conflict / active | WAIT_ANY / WAVE_CYCLES |", "|---|---|---|---|---|---|---|"]
     for k, (c, us) in a.items():
         if "attn" not in k or "delta" in k:
@@ -97,6 +100,16 @@ def pmc_md():
         out.append(f"| `{k}` | {us:.0f} | {cyc / us / 1e3:.2f} | {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.0f} | "
                    f"{c['SQ_LDS_IDX_ACTIVE'] / 256 / cyc * 100:.0f} | {c['SQ_LDS_BANK_CONFLICT'] / max(1, c['SQ_LDS_IDX_ACTIVE']):.2f} | "
                    f"{c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f} |")
+    ai = pmc("attn_inst") if glob.glob(f"{src}/attn_inst/*counter_collection.csv") else {}
+    if ai:
+        out += ["", "Instruction mix per dispatch (millions of wave-instructions; ACTIVE / WAIT in millions of quad-cycles):", "",
+                "| kernel | MFMA | VALU | LDS | SALU | VMEM rd | VALU per MFMA | ACTIVE_INST_VALU | ACTIVE_INST_LDS | WAIT_INST_LDS |", "|---|---|---|---|---|---|---|---|---|---|"]
+        for k, (c, us) in ai.items():
+            if "attn" not in k or "delta" in k:
+                continue
+            out.append(f"| `{k}` | {c['SQ_INSTS_MFMA'] / 1e6:.2f} | {c['SQ_INSTS_VALU'] / 1e6:.2f} | {c['SQ_INSTS_LDS'] / 1e6:.2f} | "
+                       f"{c['SQ_INSTS_SALU'] / 1e6:.2f} | {c['SQ_INSTS_VMEM_RD'] / 1e6:.2f} | {c['SQ_INSTS_VALU'] / max(1.0, c['SQ_INSTS_MFMA']):.2f} | "
+                       f"{c['SQ_ACTIVE_INST_VALU'] / 1e6:.1f} | {c['SQ_ACTIVE_INST_LDS'] / 1e6:.1f} | {c['SQ_WAIT_INST_LDS'] / 1e6:.1f} |")
     open(dst + "_pmc.md", "w").write("\n".join(out) + "\n")
     json.dump({"kernel": "gemm_256_kernel<0>", "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
                "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo,
@@ -108,3 +121,5 @@ stats_md()
 pmc_md()
 os.system(f"cp {src}/kernel_microbench.jsonl {dst}_kernel_microbench.jsonl; grep -h weighted8 {src}/gemm_shapes.json > {dst}_gemm_shapes.json")
 os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
+if os.path.exists(f"{src}/attn_bench.jsonl"):
+    os.system(f"cp {src}/attn_bench.jsonl {dst}_attn_bench.jsonl")
