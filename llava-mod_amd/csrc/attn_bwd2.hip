@@ -509,24 +509,21 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 
 // Causal work per owner block is linear in its index (dQ: grows, dK/dV: shrinks): every workgroup takes a pair of blocks
 // from opposite ends, so all workgroups carry the same number of tiles.
+// Grid (heads, owner blocks, batch), head fastest: see attn_fwd2.hip — the workgroups of one head share an XCD's L2.
 template <bool DKV, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p, int gx, int gy, int gz) {
+__global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // 1-D grid, XCD-aware: the workgroups of one (batch, head) — which stream the same Q / dO (K / V) rows — are adjacent logical
-  // ids and every XCD takes one contiguous chunk of logical ids, so they share one private L2.
-  const int lid = xcd_remap(blockIdx.x, gx * gy * gz);
-  const int x = lid % gx, y = (lid / gx) % gy, z = lid / (gx * gy);
   if constexpr (CAUSAL) {
-    const int nb = (p.S + 255) / 256;
+    const int nb = (p.S + 255) / 256, x = blockIdx.y;
     const int npass = (2 * x + 1 < nb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true>(p, smem, pass ? small : big, y, z);
+      bwd2_block<DKV, true>(p, smem, pass ? small : big, blockIdx.x, blockIdx.z);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false>(p, smem, x, y, z);
+    bwd2_block<DKV, false>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
   }
 }
 
@@ -540,12 +537,12 @@ void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream) {
     attr = true;
   }
   const int nb = (p.S + 255) / 256, nkv = p.nh / p.group, gx = causal ? (nb + 1) / 2 : nb;
-  const dim3 gq(gx * p.nh * p.B), gk(gx * nkv * p.B);
+  const dim3 gq(p.nh, gx, p.B), gk(nkv, gx, p.B);
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p, gx, p.nh, p.B);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p, gx, nkv, p.B);
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p);
   } else {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p, gx, p.nh, p.B);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p, gx, nkv, p.B);
+    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p);
   }
 }

@@ -533,23 +533,22 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
 
 // Causal work per query block grows linearly with its index: every workgroup takes the pair (nqb-1-x, x), so all
 // workgroups carry the same number of K/V tiles and the launch has no ragged tail.
+// Grid (heads, query blocks, batch): the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so with the
+// head as the FASTEST index every workgroup of head h — all query blocks, all samples — lands on XCD h % 8 and the query
+// blocks of one (batch, head), which read the same K / V rows, share one private L2 (+3 % over the query block fastest).
 template <bool CAUSAL>
-__global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p, int gx, int gy, int gz) {
+__global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // 1-D grid, XCD-aware: the query blocks of one (batch, head) read the same K / V rows; they are adjacent logical ids and
-  // every XCD takes one contiguous chunk of logical ids, so they share one private L2.
-  const int lid = xcd_remap(blockIdx.x, gx * gy * gz);
-  const int x = lid % gx, y = (lid / gx) % gy, z = lid / (gx * gy);
   if constexpr (CAUSAL) {
-    const int nqb = (p.S + 255) / 256;
+    const int nqb = (p.S + 255) / 256, x = blockIdx.y;
     const int npass = (2 * x + 1 < nqb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
-      fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, y, z);
+      fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z);
       __syncthreads();
     }
   } else {
-    fwd2_block<false>(p, smem, x, y, z);
+    fwd2_block<false>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
   }
 }
 
@@ -562,8 +561,7 @@ void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream) {
     attr = true;
   }
   const int nqb = (p.S + 255) / 256;
-  const int gx = causal ? (nqb + 1) / 2 : nqb;
-  const dim3 grid(gx * p.nh * p.B);
-  if (causal) hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(512), lds, stream, p, gx, p.nh, p.B);
-  else hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(512), lds, stream, p, gx, p.nh, p.B);
+  const dim3 grid(p.nh, causal ? (nqb + 1) / 2 : nqb, p.B);
+  if (causal) hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(512), lds, stream, p);
 }
