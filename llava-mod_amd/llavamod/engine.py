@@ -185,7 +185,10 @@ class DataParallel:
     of the final micro-batch."""
 
     def __init__(self, bucket_bytes=512 << 20, overlap=True, zero2=False, grad_dtype=torch.float32, min_shard_numel=1 << 16):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # LMOD_DP_FORCE=1: run the whole exchange path (RCCL collectives, shard plan, all-gather) even in a world of ONE rank —
+        # how the N>1 code is exercised on a single-GPU box (tests/test_step_parity_gpu.py)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("LMOD_DP_FORCE") == "1")
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self.bucket = bucket_bytes // 4

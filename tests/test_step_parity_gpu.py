@@ -741,6 +741,77 @@ def _nccl_zero2_worker(rank, world, port, q):
     q.put((rank, bad))
 
 
+def _rccl_world1_worker(port, q):
+    import os
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", LMOD_FORCE_DIST="1", LMOD_DP_FORCE="1")
+    import torch.distributed as dist
+    from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
+    from llavamod.train.align_trainer import AlignTrainer
+    rank, local, world = init_distributed()
+    assert dist.get_backend() == "nccl" and world == 1
+    vc, sc, tc = small_cfgs()
+    ssd, tsd = U.load_golden("gpusmall_student.safetensors"), U.load_golden("gpusmall_teacher.safetensors")
+    g = U.load_golden("gpusmall_mimic.safetensors")
+    batches = [_batch_from(g, "plain"), _batch_from(g, "ragged_kdlm")]
+    res = {}
+    for mode in ("plain", "allreduce", "zero2", "zero2_bf16"):
+        student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, "cuda:0")
+        for m in student.moe_layers():
+            m.deterministic = True
+        tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                                   loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=512)
+        gb = GradBuffer(student)
+        if mode == "plain":
+            dp = None
+        else:
+            dp = DataParallel(zero2=mode.startswith("zero2"), min_shard_numel=1,
+                              grad_dtype=torch.bfloat16 if mode.endswith("bf16") else torch.float32).attach(gb)
+            assert dp.enabled and dp.zero2 == mode.startswith("zero2")
+        opt = HipAdamW(gb, lr=1e-3, weight_decay=0.01, dp=dp, max_grad_norm=1.0)
+        hp = torch.cuda.Stream(priority=-1)                      # the step runs on a high-priority stream, as in bench.py
+        hp.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(hp):
+            for i in range(3):
+                gb.zero()
+                for a in range(2):                               # accumulation window of 2
+                    if dp is not None:
+                        dp.armed = (a == 1)
+                    tr.training_step(student, batches[(i + a) % 2])
+                if dp is not None:
+                    dp.finish()
+                opt.step(grad_scale=0.5, clear_grads=True)
+        torch.cuda.synchronize()
+        res[mode] = {k: v.detach().float().cpu() for k, v in student.state_dict().items()}
+    bad = {}
+    for mode in ("allreduce", "zero2"):                          # one rank: the exchange is the identity -> identical weights
+        bad[mode] = [k for k in res["plain"] if not torch.equal(res["plain"][k], res[mode][k])]
+    far = [k for k in res["plain"] if (res["plain"][k] - res["zero2_bf16"][k]).abs().max() > 2.5e-3]   # lr-sized Adam steps
+    bad["zero2_bf16"] = far
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(bad)
+
+
+def test_single_rank_rccl_exchange_paths_are_exact():
+    """The N>1 code on ONE GPU (the GPU box has one): an RCCL process group of world size 1 with the exchange forced on
+    (LMOD_DP_FORCE) runs the bucketed all-reduce, the in-place reduce-scatter / sharded AdamW / in-place all-gather and the
+    bf16-staged exchange through real RCCL calls on the real streams (high-priority compute stream, RCCL's own stream,
+    readiness hooks, 2-micro-batch accumulation window).  With one rank every collective is the identity, so the weights
+    after 3 optimizer steps must equal the no-DP run bit for bit (bf16 exchange: up to bf16 rounding of the gradients)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, p.exitcode
+    bad = q.get(timeout=5)
+    assert not any(bad.values()), {k: v[:4] for k, v in bad.items()}
+
+
 def test_two_gpu_zero2_equals_allreduce_over_rccl():
     """N = 2 over RCCL on real devices: ZeRO-2 style sharded step == all-reduce step (self-skips on a 1-GPU box; the
     CPU twin is tests/test_dp_gloo.py)."""
