@@ -21,7 +21,8 @@
 //                 phase B  P(j-1)·V(j-1)    16 MFMAs interleaved with the online softmax of tile j (max, deferred
 //                                           rescale decision, 32 exp2, bf16 packing): the matrix pipe works on the previous
 //                                           tile while the VALU turns this tile's scores into probabilities
-//   global -> register loads of K(j+1), V(j) are issued at the top of iteration j, written to LDS at its end.
+//   staging: the registers holding K(j+1), V(j) are written to LDS at the TOP of iteration j (right after the barrier) and the
+//   loads of K(j+2), V(j+1) re-issued at once (one register set per tensor).
 // Rescale is deferred (threshold F2_THR in log2 units): the running max moves only when some row of the wave grows by
 // more than the threshold, so the O-wide multiply is rare; probabilities are then bounded by 2^F2_THR instead of 1.
 #include "attn_common.h"
@@ -459,15 +460,24 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     }
   };
 
-  // ---- prologue: K(0) -> LDS
-  if (ntiles > 0) { gload_k(0); write_k(0); }
+  // ---- prologue: K(0) -> LDS; K(1) and V(0) in flight towards the staging registers
+  if (ntiles > 0) {
+    gload_k(0); write_k(0);
+    if (ntiles > 1) gload_k(1);
+    gload_v(0);
+  }
   __syncthreads();
 
+  // Staging (one register set per tensor): the registers hold K(j+1) and V(j), loaded during iteration j-1.  They are written
+  // to LDS right AFTER the barrier that ended iteration j-1 (their buffers' last readers are done) and the loads of K(j+2),
+  // V(j+1) are re-issued at once: the loads get a whole iteration to land, the ds_writes overlap this iteration's MFMAs, and
+  // only the barrier follows the last MFMA (written before the barrier they sat serialised behind the MFMAs).
   for (int j = 0; j <= ntiles; ++j) {
-    const bool stage_k = (j + 1 < ntiles), stage_v = (j < ntiles);
     if (F2_ABL != 5) {
-      if (stage_k) gload_k(j + 1);
-      if (stage_v) gload_v(j);
+      if (j + 1 < ntiles) write_k((j + 1) & 1);
+      if (j < ntiles) write_v(j & 1);
+      if (j + 2 < ntiles) gload_k(j + 2);
+      if (j + 1 < ntiles) gload_v(j + 1);
     }
     const bool do_a = (j < ntw), do_pv = (j >= 1 && j <= ntw);
     // masked when the key's position inside the tile exceeds mthr (covers the causal diagonal and the key length)
@@ -494,10 +504,6 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     if (j >= 1) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vaddr[dt] ^= F2_TB;
-    }
-    if (F2_ABL != 5) {
-      if (stage_k) write_k((j + 1) & 1);
-      if (stage_v) write_v(j & 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (F2_ABL != 1) __builtin_amdgcn_s_barrier();
