@@ -158,9 +158,21 @@ def linear_fwd(x, fw, act=0, out=None):
 
 
 def linear_dgrad(dy, fw):
-    """dx = dy @ W  (NT GEMM against the cached W^T [K_in, N_pad])."""
+    """dx = dy @ W  (NT GEMM against the cached W^T [K_in, N_pad]).
+    Few output tiles over a very long reduction with a nearly empty tail round — the student's lm_head dgrad: [8208 loss
+    rows x 2048] over K = 151936 is 33 x 8 = 264 tiles of 256x256, i.e. one full round of the 256 CUs plus 8 workgroups that
+    run a second, 3 ms round alone — go through the deterministic split-K entry point into an fp32 image and are cast back
+    (6.3 -> ~4 ms)."""
     wt = fw.transposed()
-    return K.gemm_nt(dy, wt, M=dy.shape[0], N=wt.shape[0], K=fw.w.shape[0], lda=dy.stride(0), ldb=wt.stride(0))
+    M, N, Kd = dy.shape[0], wt.shape[0], fw.w.shape[0]
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if Kd >= 32768 and 256 < tiles < 512 and tiles % 256 <= 64 and M >= 256 and N >= 256 and N % 16 == 0:
+        acc = torch.zeros(M, N, device=dy.device, dtype=torch.float32)
+        K.gemm_wgrad(dy if dy.shape[1] == Kd else dy[:, :Kd], wt if wt.shape[1] == Kd else wt[:, :Kd], acc)
+        out = torch.empty(M, N, device=dy.device, dtype=BF16)
+        K.cast_f32_bf16(acc.view(-1), out.view(-1))
+        return out
+    return K.gemm_nt(dy, wt, M=M, N=N, K=Kd, lda=dy.stride(0), ldb=wt.stride(0))
 
 
 def linear_wgrad(dy, x, fw):

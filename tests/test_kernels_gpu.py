@@ -246,6 +246,23 @@ def test_gemm_wgrad_splitk_deterministic(M, N, Kd):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_long_k_few_tile_dgrad_takes_split_k():
+    """ops.linear_dgrad: 33 x 8 tiles (one full round of the chip + a nearly empty second one) over K >= 32768 — the lm_head
+    dgrad shape class — goes through the deterministic split-K entry point + a cast; same result as the plain NT GEMM."""
+    from llavamod import ops
+    M, N, Kd = 8208, 2048, 32768
+    dy, wt = rnd(M, Kd, seed=21, scale=0.05), rnd(N, Kd, seed=22, scale=0.05)
+    fw = type("FW", (), {"transposed": lambda self: wt, "w": torch.empty(Kd, 1)})()
+    got = ops.linear_dgrad(dy, fw)
+    ref = K.gemm_nt(dy, wt)
+    assert got.dtype == BF and got.shape == (M, N)
+    close(got, ref.float(), "split-K dgrad vs NT", rtol=2 ** -7, afrac=2 ** -8)
+    again = ops.linear_dgrad(dy, fw)
+    assert torch.equal(got, again)                           # deterministic
+    r64 = dy[:64].double().cpu() @ wt.double().cpu().T
+    close(got[:64], r64.float().to(DEV), "split-K dgrad vs fp64", rtol=2 ** -7, afrac=2 ** -8)
+
+
 def test_transpose():
     for (R, C) in [(64, 64), (100, 72), (7, 8), (513, 1032)]:
         x = rnd(R, C, seed=R)
