@@ -367,8 +367,11 @@ def test_finetune_student_and_top1_step():
     _check_grads(_grads_of(s1), ograds, 3e-2, 5e-2)
 
 
-def test_trainable_norms_and_embedding_step():
-    """A run that unfreezes the decoder's RMSNorm scales and embed_tokens (not the distillation shells' train_modules, but
+@pytest.mark.parametrize("everything", [False, True])
+def test_trainable_norms_and_embedding_step(everything):
+    """everything=True: empty `train_modules` (the reference's default: every decoder / projector parameter trainable —
+    attention q/k/v/o with biases, lm_head, norms, embeddings; the CLIP tower stays frozen as in clip_encoder.py:31).
+    A run that unfreezes the decoder's RMSNorm scales and embed_tokens (not the distillation shells' train_modules, but
     reachable through --train_modules / FineTune): their gradients come from lmod_rmsnorm_dw / lmod_embed_wgrad and match the
     oracle's, alongside the usual set; a parameter with no gradient kernel (CLIP tower) raises at GradBuffer construction."""
     from llavamod.engine import GradBuffer
@@ -379,7 +382,7 @@ def test_trainable_norms_and_embedding_step():
     student, teacher = U.build_hip_pair(ssd, tsd, sc, tc, vc, DEV)
     extra = ("layernorm.weight", "model.norm.weight", "embed_tokens.weight")
     for n, p in student.named_parameters():
-        if any(n.endswith(e) for e in extra) and "image_tower" not in n:
+        if (everything or any(n.endswith(e) for e in extra)) and "image_tower" not in n:
             p.requires_grad = True
     for m in student.moe_layers():
         m.deterministic = True
@@ -388,7 +391,7 @@ def test_trainable_norms_and_embedding_step():
     o_student.load_state_dict(ssd); o_teacher.load_state_dict(tsd)
     freeze_like_d2s(o_student)
     for n, p in o_student.named_parameters():
-        if any(n.endswith(e) for e in extra) and "image_tower" not in n:
+        if (everything or any(n.endswith(e) for e in extra)) and "image_tower" not in n:
             p.requires_grad_(True)
     ob = {k: g["ragged_kdlm.batch." + k] for k in ("input_ids", "attention_mask", "labels", "images")}
     ob["attention_mask"] = ob["attention_mask"].bool()
