@@ -330,7 +330,29 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   if (SPLIT_OK && p.splitk > 1) {      // split-major: an XCD's contiguous chunk is many tiles of ONE K split (same L2 reuse)
     split = bz; bz = 0; id -= split * tpb;
   }
-  const int r = id - bz * tpb;
+  int r = id - bz * tpb;
+  if (MODE == 0 && p.k_valid && !p.m_valid && p.batch > 1 && p.batch <= GEMM_MAX_GROUPS && p.splitk <= 1 && !(tpb & 7)) {
+    // Batched weight gradients with a different live reduction length per batch (MoE experts: k_valid = routed rows).
+    // The generic mapping hands each XCD ONE contiguous chunk of (batch, tile) ids, i.e. whole experts: with routed-row
+    // counts of 9k / 12k / 20k / 24k the XCDs holding the long experts ran 2.7x longer than the others (880 TF against
+    // 1240 TF for the same flops, balanced).  Here every XCD takes 1/8 of EVERY expert's tiles (still a contiguous run of
+    // tiles per expert: same L2 reuse), longest reduction first so that the short tiles fill the tail.
+    const int tpb8 = tpb >> 3, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int rnk = k / tpb8;
+    int sel = rnk;
+    for (int e = 0; e < p.batch; ++e) {
+      const int ke = p.k_valid[e];
+      int rank = 0;
+      for (int f = 0; f < p.batch; ++f) {
+        const int kf = p.k_valid[f];
+        rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+      }
+      if (rank == rnk) sel = e;
+    }
+    bz = sel;
+    r = xcd * tpb8 + (k - rnk * tpb8);
+    id = bz * tpb + r;
+  }
   const int GROUP_M = G256_GROUP_M;
   const int grp = r / (GROUP_M * p.tiles_n);
   const int first_m = grp * GROUP_M;

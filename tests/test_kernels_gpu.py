@@ -246,6 +246,22 @@ def test_gemm_wgrad_splitk_deterministic(M, N, Kd):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("E,M,N,Kd,kv", [(3, 2048, 256, 512, [512, 64, 200]), (4, 1024, 512, 320, [8, 320, 0, 168]),
+                                         (5, 768, 256, 256, [256, 256, 104, 32, 256])])
+def test_gemm_batched_kvalid_balanced_xcd_mapping(E, M, N, Kd, kv):
+    """Batched fp32-accumulate NT GEMM with a live reduction length per batch (MoE expert weight gradients).  With a tile
+    count per batch divisible by 8 the kernel deals every XCD 1/8 of EVERY batch's tiles, longest reduction first (cases 1, 2);
+    otherwise the generic mapping (case 3).  Every (batch, tile) must be computed exactly once, over its own k_valid (a multiple of 8 here: the NT form reads whole 16-byte groups, callers zero-pad)."""
+    a, b = rnd(E, M, Kd, seed=31, scale=0.1), rnd(E, N, Kd, seed=32, scale=0.1)
+    base = torch.randn(E, M, N, device=DEV)
+    out = base.clone()
+    rows = torch.tensor(kv, device=DEV, dtype=torch.int32)
+    K.gemm_nt(a, b, out=out, out_f32=True, accumulate=True, k_valid=rows)
+    for e in range(E):
+        ref = base[e].double() + a[e, :, :kv[e]].double() @ b[e, :, :kv[e]].double().T
+        close(out[e], ref.float(), f"batch {e}", rtol=1e-4, afrac=1e-5)
+
+
 def test_long_k_few_tile_dgrad_takes_split_k():
     """ops.linear_dgrad: 33 x 8 tiles (one full round of the chip + a nearly empty second one) over K >= 32768 — the lm_head
     dgrad shape class — goes through the deterministic split-K entry point + a cast; same result as the plain NT GEMM."""
