@@ -491,6 +491,8 @@ def _attn_ref(q, k, v, scale, causal, seqlens):
     (2, 300, 2, 1, 128, False, True),          # hd-128 forward kernel: non-causal, ragged keys, S % 32 != 0, GQA
     (1, 1000, 3, 3, 128, True, False),         # S % 64 != 0, several query blocks, odd head count
     (2, 77, 2, 2, 128, False, False),          # shorter than one query block
+    (1, 1100, 4, 1, 128, True, False),         # 5 owner blocks (odd: the middle one is a single pass), GQA group of 4
+    (2, 520, 4, 1, 128, False, True),          # non-causal GQA group of 4 with a ragged key mask, 3 owner blocks
 ])
 def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
     ld = (nh + 2 * nkv) * hd
