@@ -68,6 +68,8 @@ def main():
 
     def spin():
         exe = os.path.join(ROOT, "tools", "probe", "mfma_power")
+        if not os.path.exists(exe):                          # the binary is not tracked: build it from the source beside it
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", exe, exe + ".hip"], check=True)
         out = subprocess.run([exe, "120"], capture_output=True, text=True, timeout=120).stdout.strip().split("\n")
         tf = {16: [], 32: []}
         for l in out:
