@@ -44,7 +44,7 @@
 #define F2_PIN(x) asm volatile("" : "+v"(x))
 #ifndef F2_ABL
 #define F2_ABL 0                   // timing ablations (WRONG RESULTS): 1 no barrier, 2 no exponentials, 3 no P·V MFMAs, 4 no QK^T MFMAs,
-#endif                             //   5 no global->LDS staging, 6 no operand reads from LDS
+#endif                             //   5 no global->LDS staging, 6 no operand reads from LDS, 7 no row sum
 #define F2_SB() do { if (F2_SCHED) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // O^T accumulators: a[0:63], OWNED BY INLINE ASM for the lifetime of a query block (strip dt = a[16dt : 16dt+15]).  They are
@@ -343,7 +343,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     for (int e = e0; e < e0 + 2; ++e) {
       const float pv = (F2_ABL == 2) ? s[KT][e] : __builtin_amdgcn_exp2f(__builtin_fmaf(s[KT][e], c, nmc));
       s[KT][e] = pv;
-      rs += pv;
+      if (F2_ABL != 7) rs += pv;                               // ablation 7: no row sum
     }
     F2_PIN(rs);
     if ((e0 & 7) == 6) {
