@@ -1324,6 +1324,9 @@ int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, voi
 #define WGRAD_MAX_TILES 4096
 static int wgrad_pick_split(int M, int N, int K, int max_s) {
   if (M < 256 || N < 256 || K < 4096 || (N & 15)) return 1;
+  static int forced = -1;              // LMOD_WGRAD_SPLIT=s: force the split (tuning of the cost model below)
+  if (forced < 0) { const char* e = getenv("LMOD_WGRAD_SPLIT"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced < max_s ? forced : max_s;
   const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
   if (t256 >= 512 || t256 > WGRAD_MAX_TILES) return 1;
   int best_s = 1;
