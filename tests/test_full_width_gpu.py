@@ -162,3 +162,52 @@ def test_gemm_256_tile_deep_k_vs_fp32(M, N, K_):
         assert bool((err <= bound).all()), (r0, err.max().item(), ref.abs().max().item())
         worst = max(worst, (err / ref.abs().max()).max().item())
     assert worst <= 2 ** -8
+
+
+def test_config2_full_depth_step_properties():
+    """The FULL config-2 models (24-layer 4-expert MoE student, 32-layer 7B teacher, CLIP-L/14-336 towers; random init as in
+    bench.py) through one mimic step at B = 1, S = 2048: properties that do not need the oracle —
+    finite loss that decomposes as align + lm + moe_balance (lm already carries the balance term: align + ce + 2 moe), every MoE
+    layer's first-choice counts sum to T and no expert exceeds its capacity, a positive finite gradient norm, and the whole
+    step (loss bits, every gradient element) identical across two runs from the same state.  The numerical comparison of this
+    depth against the fp32 oracle lives in bench.py's cpu_baseline (loss_delta, profiles/r02_final_bench_n1.json)."""
+    import importlib.util
+    from llavamod.engine import GradBuffer
+    from llavamod.model import LLaVAMoDQwen2ForCausalLM, LlavaQwen2ForCausalLM
+    from llavamod.train.align_trainer import AlignTrainer
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    student = LLaVAMoDQwen2ForCausalLM(bench.student_cfg(4), device=DEV)
+    student.initialize_moe_modules(bench.moe_model_args(4))
+    teacher = LlavaQwen2ForCausalLM(bench.teacher_cfg(), device=DEV)
+    gb = GradBuffer(student)
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))())
+    batch = bench.synthetic_batch(1, seed=7)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for m in student.moe_layers():
+        m.deterministic = True                                  # no gating noise: the two runs must route identically
+    student.train()
+    runs = []
+    for _ in range(2):
+        gb.zero()
+        loss, outs = tr.compute_loss(student, batch, return_outputs=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {k: v.detach().clone() for k, v in outs.items()}, gb.flat.clone()))
+    loss, outs, grads = runs[0]
+    assert torch.isfinite(loss) and float(loss) > 0
+    parts = float(outs["loss/align"]) + float(outs["loss/lm"]) + float(outs["loss/moe_balance"])
+    assert abs(float(outs["loss"]) - parts) <= 1e-5 * abs(parts), (float(outs["loss"]), parts)
+    T = 2048
+    moes = student.moe_layers()
+    assert len(moes) == 12
+    for m in moes:
+        st = m.last_state
+        assert int(st.exp_counts.sum()) == T, int(st.exp_counts.sum())
+        assert int(st.slots_used.max()) <= st.C == 1536 and int(st.slots_used.sum()) <= 2 * T
+    gn = float(grads.double().norm())
+    assert gn > 0 and gn == gn and gn < float("inf")
+    assert torch.equal(runs[0][0], runs[1][0]), "loss differs between two runs"
+    assert torch.equal(runs[0][2], runs[1][2]), "gradients differ between two runs"
