@@ -1,7 +1,15 @@
 #!/usr/bin/env python
 """bench.py — distillation training-step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched one process per GPU by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or started plainly — `python bench.py --gpus N` then
+re-executes itself under torch.distributed.run on 127.0.0.1 (the reference's one-command launch,
+shells/train/qwen/dense2sparse_distillation.sh:48 `deepspeed llavamod/train/align_train.py ...`).
+`--launch-check`: every rank rendezvouses over the selected backend (RCCL; `LMOD_DIST_BACKEND=gloo` on a box without GPUs),
+builds the REAL config's span / shard / optimizer-state plan on `meta` tensors, proves the world with one collective and
+prints the `exchange` object — the N>1 plumbing without touching a GPU.
 
 One "step" = one full mimic-distillation OPTIMIZER step (config 2 of BASELINE.json: CLIP-ViT-L/14-336 +
 Qwen-1.8B-MoE top-2/4-expert student, Qwen-7B dense teacher, bf16): `--grad-accum` (default 2) micro-batches
@@ -197,6 +205,88 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto"):
     return out
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher environment: become `torch.distributed.run` with one process per GPU
+    on this node (rendezvous on 127.0.0.1 — the container hostname may not resolve)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this driver
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def exchange_object(dp, opt, steps, comm0=None):
+    """What the data-parallel step exchanges: backend and world as torch.distributed reports them (so the line shows RCCL
+    had N ranks), the static per-step plan of this rank, and — after a timed run — the collectives actually issued per step."""
+    from llavamod import engine
+    on = dist.is_available() and dist.is_initialized()
+    ex = {"backend": ("rccl (torch 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()) if on else None,
+          "world_seen_by_backend": dist.get_world_size() if on else 1,
+          "zero2": bool(dp.zero2), "grad_dtype": "bf16" if dp.grad_dtype == torch.bfloat16 else "fp32",
+          "ep_size": dp.ep_size, "overlap": "spans exchanged from wgrad-ready hooks on RCCL's own high-priority stream"}
+    if dp.enabled:
+        ex["plan"] = dp.exchange_plan()
+    if steps and dp.enabled:
+        base = comm0 or {}
+        ex["issued_per_step"] = {k: {"calls": round((v[0] - base.get(k, [0, 0])[0]) / steps, 2),
+                                     "bytes": int((v[1] - base.get(k, [0, 0])[1]) / steps)}
+                                 for k, v in sorted(engine.COMM.items())}
+    return ex
+
+
+def launch_check(args):
+    """N>1 plumbing without hardware: rendezvous, world proof, span plan of the real architecture on `meta`."""
+    from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
+    from llavamod.model import LLaVAMoDQwen2ForCausalLM
+    rank, local, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == 1 or (dist.is_initialized() and dist.get_world_size() == world)
+    cdev = torch.device("cuda", local) if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
+    if world > 1:                                             # one real collective over the chosen backend: every rank is there
+        seen = torch.zeros(world, device=cdev)
+        seen[rank] = 1.0
+        dist.all_reduce(seen)
+        assert bool((seen == 1).all()), seen
+    student = LLaVAMoDQwen2ForCausalLM(student_cfg(args.experts), device="meta")
+    student.initialize_moe_modules(moe_model_args(args.experts, ep_size=args.ep))
+    for p in student.get_model().mm_projector.parameters():
+        p.requires_grad = True
+    gb = GradBuffer(student)
+    dp = DataParallel(zero2=not args.no_zero2, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
+                      ).attach(gb, args.ep)
+    opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0, dp=dp, max_grad_norm=args.max_grad_norm or None)
+    if world > 1:
+        # every rank must have laid out the same spans, and the owned chunks must tile each span exactly once per group
+        sizes = torch.tensor([n for _, _, n in gb.spans] + [gb.numel], dtype=torch.int64, device=cdev)
+        ref = sizes.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, sizes), "ranks disagree on the gradient-buffer layout"
+        owned = torch.tensor([float(i["hi"] - i["lo"]) if i["sharded"] else 0.0 for i in dp.plan.values()],
+                             dtype=torch.float64, device=cdev)
+        dist.all_reduce(owned)
+        full = torch.tensor([float(i["n"]) * (world // i["gsize"]) if i["sharded"] else 0.0 for i in dp.plan.values()],
+                            dtype=torch.float64, device=cdev)
+        assert torch.equal(owned, full), "sharded chunks do not tile their spans"
+    n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
+    if rank == 0:
+        print(json.dumps({"launch_check": "ok", "n_gpus": world, "stage": args.stage, "trainable_params": n_train,
+                          "grad_buffer_elems": gb.numel, "optimizer_state_elems_rank0": opt.n_state,
+                          "exchange": exchange_object(dp, opt, 0)}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,8 +315,15 @@ def main():
     ap.add_argument("--ep", type=int, default=1, help="expert-parallel group size (config 5: --experts 8 --ep 8)")
     ap.add_argument("--stage", default="mimic", choices=["mimic", "dpo"],
                     help="mimic = configs 2/3/5 (headline metric); dpo = config 4 (preference distillation, pairs/s)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + world proof + the real config's exchange plan on meta tensors, then exit (no GPU work)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args.gpus)                                # does not return
+    if args.launch_check:
+        return launch_check(args)
 
+    from llavamod import engine
     from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed, warmup_cosine
     from llavamod.model import LLaVAMoDQwen2ForCausalLM, LlavaQwen2ForCausalLM
     from llavamod.train.align_trainer import AlignTrainer
@@ -311,6 +408,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    comm0 = {k: list(v) for k, v in engine.COMM.items()}
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -388,6 +486,7 @@ def main():
                          "whole_step": {"achieved": round(achieved, 1), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                                         "basis": f"{ledger:.2f} algorithmic TFLOP per unit (BASELINE.md) x units/s / n_gpus",
                                         "executed_tflop_per_sample": round(executed_tflop_per_sample(), 2)}},
+            "exchange": exchange_object(dp, opt, args.steps, comm0),
         }
         if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:

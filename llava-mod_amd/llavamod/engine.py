@@ -17,6 +17,17 @@ from .ops import FusedWeight
 BF16 = torch.bfloat16
 
 
+# name -> [calls, payload bytes handed to the collective on this rank] since process start (bench.py reports them per step
+# in its `exchange` object, next to the static plan: evidence of what RCCL was actually asked to move)
+COMM = {}
+
+
+def comm_count(name, tensor):
+    c = COMM.setdefault(name, [0, 0])
+    c[0] += 1
+    c[1] += tensor.numel() * tensor.element_size()
+
+
 _EP_GROUPS = {}
 
 
@@ -261,10 +272,12 @@ class DataParallel:
             flat = self._gbf
             self._castback.append((info["lo"], info["hi"]))
         if info["sharded"]:
+            comm_count("reduce_scatter", flat[off:off + n])
             self._handles.append(dist.reduce_scatter_tensor(flat[info["lo"]:info["hi"]], flat[off:off + n],
                                                             op=dist.ReduceOp.SUM, group=g, async_op=True))
         else:
             for a in range(off, off + n, self.bucket):
+                comm_count("all_reduce", flat[a:min(a + self.bucket, off + n)])
                 self._handles.append(dist.all_reduce(flat[a:min(a + self.bucket, off + n)], op=dist.ReduceOp.SUM, group=g,
                                                      async_op=True))
 
@@ -286,6 +299,32 @@ class DataParallel:
             for lo, hi in self._castback:
                 K.cast_f32_bf16(self._gbf[lo:hi], self.gb.flat[lo:hi])
         self._handles, self._done, self._castback = [], set(), []
+
+    def exchange_plan(self):
+        """Static summary of what one optimizer step exchanges on this rank (from the span plan alone — computable on `meta`
+        tensors): per collective the number of calls and the payload bytes this rank hands to RCCL."""
+        gsz = 2 if self.grad_dtype == BF16 else 4
+        out = {"reduce_scatter": [0, 0], "all_reduce": [0, 0], "all_gather": [0, 0]}
+        sharded_elems = replicated_elems = local_elems = 0
+        for (kind, obj, n) in self.gb.spans:
+            info = self.plan[(id(obj), kind)]
+            if not info["exchange"]:
+                local_elems += n
+                continue
+            if info["sharded"]:
+                out["reduce_scatter"][0] += 1
+                out["reduce_scatter"][1] += n * gsz
+                out["all_gather"][0] += 1
+                out["all_gather"][1] += n * 2                  # bf16 working weights, in place
+                sharded_elems += n
+            else:
+                out["all_reduce"][0] += -(-n // self.bucket)
+                out["all_reduce"][1] += n * gsz
+                replicated_elems += n
+        return {"collectives_per_step": {k: {"calls": v[0], "bytes": v[1]} for k, v in out.items()},
+                "spans": len(self.gb.spans), "sharded_params": sharded_elems, "replicated_params": replicated_elems,
+                "rank_local_params": local_elems,
+                "optimizer_state_params_this_rank": sum(i["hi"] - i["lo"] for i in self.plan.values())}
 
     def all_reduce(self, flat, n_dense=None, ep_size=1):
         """Non-overlapped all-reduce form: SUM over the DP world for the first n_dense elements (replicated parameters);
@@ -319,6 +358,11 @@ class HipAdamW:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         dev = gb.flat.device
+        if dp is not None and dp.enabled and dp.gb is not gb:
+            # the shard layout (who owns which chunk of the master / m / v) comes from dp.attach(gb): an optimizer built
+            # before it would keep full-span state and update it from reduce-scattered (partially un-reduced) gradients
+            raise RuntimeError("HipAdamW(dp=...): call dp.attach(gb) on THIS GradBuffer before constructing the optimizer")
+        self._weights_epoch = getattr(gb.model, "_weights_epoch", 0)
         self.items = []                         # (kind, obj, lo, hi, state offset, counted in global reductions)
         soff = 0
         for (kind, obj, n), off in zip(gb.spans, gb.offsets):
@@ -375,6 +419,7 @@ class HipAdamW:
         if first:
             self._ss.zero_()
         if self.dp is not None and self.dp.enabled:
+            comm_count("all_reduce_scalar", self._ss)
             dist.all_reduce(self._ss, op=dist.ReduceOp.SUM)
         K.clip_coef(self._ss, grad_scale, self.max_grad_norm, self._coef, self.grad_norm)
         return self._coef
@@ -385,6 +430,12 @@ class HipAdamW:
         them, each one publishing an event that `FusedWeight.ensure()` waits on; every span also clears its gradient in the
         same pass (GradBuffer.zero() then skips the memset).  Arithmetic and results are identical to the serial form.
         Call `sync()` before reading weights outside a forward."""
+        ep = getattr(self.gb.model, "_weights_epoch", 0)
+        if ep != self._weights_epoch:
+            # a checkpoint was loaded into the model after this optimizer took its fp32 masters (checkpoint.load_checkpoint
+            # bumps the epoch): stepping from the stale masters would overwrite the just-loaded weights
+            self.resync_master()
+            self._weights_epoch = ep
         self.step_count += 1
         lr = self.lr if lr is None else lr
         zero2 = self.dp is not None and self.dp.zero2
@@ -429,6 +480,7 @@ class HipAdamW:
             info = self.dp.plan[(id(obj), kind)]
             if info["sharded"]:
                 full = self.gb.pflat[off:off + info["n"]]
+                comm_count("all_gather", full)
                 handles.append(dist.all_gather_into_tensor(full, self.gb.pflat[lo:hi], group=info["group"], async_op=True))
         for h in handles:
             h.wait()

@@ -254,6 +254,8 @@ def init_normal_(module, std=0.02, seed=0):
     """Random-init of the named architecture (no network for checkpoints): N(0, std) everywhere except
     norm scales (1) — config 1/2 recipe of SURVEY.md §8d."""
     dev = next(module.parameters()).device
+    if dev.type == "meta":          # shape-only construction (bench.py --launch-check plans the exchange without weights)
+        return module
     g = torch.Generator(device=dev).manual_seed(seed)
     with torch.no_grad():
         for n, p in module.named_parameters():

@@ -646,7 +646,9 @@ class AllToAll(torch.autograd.Function):
         if group is None:
             return x
         import torch.distributed as dist
+        from .engine import comm_count
         out = torch.empty_like(x)
+        comm_count("all_to_all", x)
         dist.all_to_all_single(out, x.contiguous(), group=group)
         return out
 
@@ -655,7 +657,9 @@ class AllToAll(torch.autograd.Function):
         if ctx.group is None:
             return g, None
         import torch.distributed as dist
+        from .engine import comm_count
         out = torch.empty_like(g)
+        comm_count("all_to_all", g)
         dist.all_to_all_single(out, g.contiguous(), group=ctx.group)
         return out, None
 

