@@ -77,8 +77,11 @@ def read_state(path):
         if os.path.exists(idx):
             names = sorted(set(json.load(open(idx))["weight_map"].values()))
         else:
-            names = sorted(n for n in os.listdir(path) if n.endswith(".safetensors")) or \
-                    sorted(n for n in os.listdir(path) if re.fullmatch(r"pytorch_model.*\.bin", n))
+            # HF's resolution order: the single file, then numbered shards, then the torch-pickled forms
+            ls = os.listdir(path)
+            names = (["model.safetensors"] if "model.safetensors" in ls else []) or \
+                    sorted(n for n in ls if re.fullmatch(r"model-\d+-of-\d+\.safetensors", n)) or \
+                    sorted(n for n in ls if re.fullmatch(r"pytorch_model.*\.bin", n))
         if not names:
             raise FileNotFoundError(f"no model weights under {path}")
         out = {}
@@ -88,15 +91,23 @@ def read_state(path):
     return _read(path)
 
 
-def load_checkpoint(model, path, strict=True):
+def load_checkpoint(model, path, strict=True, ignore_prefixes=(), state=None):
     """Copy tensors into `model` by (normalised) name, casting to each parameter's dtype/device.  Checkpoints saved
     BEFORE up-cycling (dense `mlp.{gate,up,down}_proj`) load into an up-cycled model the way the reference's
     `initialize_moe_modules` does: every expert receives the dense FFN (`llava_qwen2_moe.py:547-556`).
+    ignore_prefixes: checkpoint AND model tensors under these names are left alone (the image tower when it was loaded
+    from its own directory).  state: the already-read {name: tensor} of `path`.  Non-persistent HF buffers
+    (`rotary_emb.inv_freq`, `position_ids`) in a checkpoint are not parameters of this tree and are skipped.
     Returns (missing, unexpected)."""
-    src = {_normalise(k): v for k, v in read_state(path).items()}
+    raw = state if state is not None else read_state(path)
+    src = {_normalise(k): v for k, v in raw.items()
+           if not (k.endswith("rotary_emb.inv_freq") or k.endswith(".position_ids"))}
+    src = {k: v for k, v in src.items() if not k.startswith(tuple(ignore_prefixes))} if ignore_prefixes else src
     own = model.state_dict()
     used, missing, plan = set(), [], []
     for k, t in own.items():                 # validate everything BEFORE touching the model: a failed load leaves it intact
+        if ignore_prefixes and k.startswith(tuple(ignore_prefixes)):
+            continue
         v = src.get(k)
         if v is None:
             m = re.match(r"(.*\.mlp\.)deepspeed_moe\.experts\.deepspeed_experts\.\d+\.(.*)", k)

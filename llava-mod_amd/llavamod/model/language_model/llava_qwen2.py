@@ -266,19 +266,43 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
                 cfg[k] = v
         cfg["model_type"] = getattr(self.config, "model_type", None)
         cfg["architectures"] = [type(self).__name__]
-        json.dump(cfg, open(os.path.join(save_directory, "config.json"), "w"), indent=1)
+        tmp = os.path.join(save_directory, "config.json.tmp")
+        with open(tmp, "w") as f:                              # temp file + rename: a crash never leaves half a config
+            json.dump(cfg, f, indent=1)
+        os.replace(tmp, os.path.join(save_directory, "config.json"))
         return save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes)
+
+    def save_mm_adapter(self, output_dir, keys_to_match=("mm_projector",)):
+        """Adapter-only save of the reference's trainers (train/align_trainer.py:616-636 `_save_checkpoint` with
+        tune_mm_mlp_adapter; train/align_train.py:623-631 `safe_save_model_for_hf_trainer`): ONLY the parameters whose name
+        contains one of `keys_to_match`, under their full names, torch-pickled as `mm_projector.bin` — the file
+        `--pretrain_mm_mlp_adapter` reads back (llava_arch.py:122-128)."""
+        import os
+        os.makedirs(output_dir, exist_ok=True)
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items() if any(m in k for m in keys_to_match)}
+        if not sd:
+            raise ValueError(f"no parameter matches {keys_to_match}")
+        path = os.path.join(output_dir, "mm_projector.bin")
+        torch.save(sd, path + ".tmp")
+        os.replace(path + ".tmp", path)
+        return path
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, attn_implementation=None, torch_dtype=None,
                         device="cuda", strict=True, config=None, cache_dir=None, **kwargs):
         """`X.from_pretrained(path, attn_implementation=...)` of the reference's entry scripts (train/align_train.py:133-139):
         read config.json, build the architecture, load the weights by name.  attn_implementation is recorded only (there is
-        one attention implementation here: the HIP flash kernels); torch_dtype must be bf16 (the compute dtype)."""
+        one attention implementation here: the HIP flash kernels); torch_dtype must be bf16 (the compute dtype).
+
+        Image tower: a tower NAMED in the config (`mm_image_tower: "<dir or hub name>"`) takes its weights from that
+        directory (also looked up relative to the checkpoint), as `CLIPVisionModel.from_pretrained` does in the reference
+        (clip_encoder.py:24-33) — `model.image_tower.*` tensors of the main checkpoint are then ignored, as the reference
+        ignores them (its tower is built with delay_load, llava_arch.py:31).  If the name is not a local directory (a hub
+        name; no network here) the main checkpoint's own `model.image_tower.*` tensors are used; if it has none, this raises."""
         import json
         import os
-        from ...checkpoint import load_checkpoint
-        from ..multimodal_encoder.clip_encoder import CLIPVisionConfig
+        from ...checkpoint import load_checkpoint, read_state
+        from ..multimodal_encoder.clip_encoder import KNOWN_GEOMETRY, CLIPVisionConfig
         if torch_dtype not in (None, torch.bfloat16):
             raise ValueError("this path computes in bf16: torch_dtype must be torch.bfloat16 (or None)")
         path = pretrained_model_name_or_path
@@ -286,7 +310,7 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             raw = json.load(open(os.path.join(path, "config.json")))
             raw.update(kwargs)
             moe = raw.pop("moe", None)
-            for drop in ("architectures", "model_type", "transformers_version", "torch_dtype", "lora"):
+            for drop in ("architectures", "model_type", "transformers_version", "torch_dtype", "dtype", "lora"):
                 raw.pop(drop, None)
             tower = raw.get("mm_image_tower")
             if isinstance(tower, dict) and "__clip_vision_config__" in tower:
@@ -295,8 +319,22 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             if moe is not None:
                 config.moe = moe
         config._attn_implementation = attn_implementation
+        config._name_or_path = path
         model = cls(config, device=device)
-        load_checkpoint(model, path, strict=strict)
+        tower, src, ignore = model.get_image_tower(), None, ()
+        if tower is not None and not tower.is_loaded:
+            try:
+                tower.load_model(search=(path,))
+                ignore = ("model.image_tower.",)
+            except FileNotFoundError as e:
+                src = read_state(path)
+                pre = "model.image_tower.image_tower."
+                tsd = {k[len(pre):]: v for k, v in src.items() if k.startswith(pre)}
+                if not tsd:
+                    raise FileNotFoundError(f"{e}; and {path} holds no `{pre}*` tensors either") from None
+                heads = KNOWN_GEOMETRY.get(tower.image_tower_name, {}).get("num_attention_heads")
+                tower.load_from_state(tsd, source=f"{path} ({pre}*)", heads=heads)
+        load_checkpoint(model, path, strict=strict, ignore_prefixes=ignore, state=src)
         return model
 
     def lm_loss_from_hidden(self, hidden, info):

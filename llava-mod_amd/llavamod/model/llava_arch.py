@@ -26,8 +26,13 @@ class LlavaMetaModel:
     """Mixin for the decoder `model` object: owns `image_tower` and `mm_projector` (llava_arch.py:27-128)."""
 
     def _init_vision(self, config, device):
-        if getattr(config, "mm_image_tower", None) is not None:
-            self.image_tower = build_image_tower(config, delay_load=False, device=device)
+        tower = getattr(config, "mm_image_tower", None)
+        if tower is not None:
+            # llava_arch.py:31: a tower NAMED in the config is built with delay_load=True (config only); its weights arrive
+            # with initialize_vision_modules().load_model() or from_pretrained.  A CLIPVisionConfig OBJECT (synthetic
+            # benchmarks / tests) builds the random-init architecture at once.
+            self.image_tower = build_image_tower(config, delay_load=isinstance(tower, str), device=device,
+                                                 search=(getattr(config, "_name_or_path", None),))
             self.mm_projector = build_projector(config, device=device)
 
     def get_image_tower(self):

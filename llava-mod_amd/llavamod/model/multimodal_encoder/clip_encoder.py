@@ -91,25 +91,152 @@ class _CLIPVisionModel(nn.Module):
         self.vision_model = _VisionModel(c, device)
 
 
+# geometry of the hub names the reference's shells pass as --image_tower (dense2sparse_distillation.sh:23); used only to
+# build the ARCHITECTURE when the weights then come from a checkpoint's own `model.image_tower.*` keys
+KNOWN_GEOMETRY = {
+    "openai/clip-vit-large-patch14-336": dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                              num_attention_heads=16, image_size=336, patch_size=14),
+    "openai/clip-vit-large-patch14": dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                          num_attention_heads=16, image_size=224, patch_size=14),
+    "openai/clip-vit-base-patch16": dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                         num_attention_heads=12, image_size=224, patch_size=16),
+    "openai/clip-vit-base-patch32": dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                         num_attention_heads=12, image_size=224, patch_size=32),
+}
+_WEIGHT_FILES = ("model.safetensors", "pytorch_model.bin")
+
+
+def resolve_tower_dir(name, search=()):
+    """A local directory holding the tower (`config.json` + weights): the name itself, or the name relative to one of
+    `search` (the main checkpoint's directory, cache_dir).  None if there is none — hub names cannot be fetched here."""
+    import os
+    if not isinstance(name, str):
+        return None
+    for base in ("",) + tuple(s for s in search if s):
+        d = os.path.join(base, name) if base else name
+        if os.path.isdir(d) and os.path.exists(os.path.join(d, "config.json")):
+            return d
+    return None
+
+
+def read_clip_config(path):
+    """`CLIPVisionConfig.from_pretrained(dir)`: a CLIPVisionModel config, or the `vision_config` of a full CLIPModel one."""
+    import json
+    import os
+    raw = json.load(open(os.path.join(path, "config.json")))
+    if isinstance(raw.get("vision_config"), dict):
+        raw = raw["vision_config"]
+    if raw.get("hidden_act", "quick_gelu") != "quick_gelu":
+        raise NotImplementedError(f"CLIP tower with hidden_act={raw['hidden_act']!r}: only quick_gelu (OpenAI CLIP) is on this path")
+    keys = ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "image_size", "patch_size",
+            "layer_norm_eps")
+    return CLIPVisionConfig(**{k: raw[k] for k in keys if k in raw})
+
+
+def normalise_clip_keys(sd):
+    """Tower weights by the names of this module tree (`vision_model.…`, HF 4.37).  Accepts a CLIPVisionModel or full
+    CLIPModel state dict in either key dialect (transformers 5.x drops the `vision_model.` level of CLIPVisionModel);
+    text tower, projections, logit scale and position-id buffers are dropped."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith(("text_model.", "text_projection", "visual_projection", "logit_scale")) or k.endswith("position_ids"):
+            continue
+        if not k.startswith("vision_model."):
+            if k.split(".")[0] in ("embeddings", "pre_layrnorm", "encoder", "post_layernorm"):
+                k = "vision_model." + k
+            else:
+                continue
+        out[k] = v
+    return out
+
+
+def geometry_from_state(sd, heads=None):
+    """CLIPVisionConfig fields from the tensor shapes of a (normalised) tower state dict.  The head count is not in any
+    shape: `heads` if given, else hidden/64 (every OpenAI CLIP ViT has 64-wide heads)."""
+    d = sd["vision_model.embeddings.class_embedding"].shape[0]
+    pw = sd["vision_model.embeddings.patch_embedding.weight"]
+    n_pos = sd["vision_model.embeddings.position_embedding.weight"].shape[0]
+    L = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("vision_model.encoder.layers."))
+    side = int(round((n_pos - 1) ** 0.5))
+    return CLIPVisionConfig(hidden_size=d, intermediate_size=sd["vision_model.encoder.layers.0.mlp.fc1.weight"].shape[0],
+                            num_hidden_layers=L, num_attention_heads=heads or max(1, d // 64),
+                            image_size=side * pw.shape[-1], patch_size=pw.shape[-1])
+
+
 class CLIPVisionTower(nn.Module):
-    def __init__(self, image_tower, args, delay_load=False, cache_dir="./cache_dir", device="cuda"):
+    """`image_tower`: a checkpoint directory / hub name (the reference's only form, clip_encoder.py:8-33) or — for
+    synthetic-weight benchmarks and tests — a `CLIPVisionConfig` object, which builds a RANDOMLY INITIALISED tower of that
+    geometry.  A string never random-initialises: it loads from a local directory or raises."""
+
+    def __init__(self, image_tower, args, delay_load=False, cache_dir="./cache_dir", device="cuda", search=()):
         super().__init__()
         self.is_loaded = False
         self.image_tower_name = image_tower
         self.select_layer = getattr(args, "mm_vision_select_layer", -2)
         self.select_feature = getattr(args, "mm_vision_select_feature", "patch")
-        self.cfg_only = image_tower if isinstance(image_tower, CLIPVisionConfig) else CLIPVisionConfig()
+        self.cache_dir = cache_dir
+        self._search = tuple(search)
         self._device = device
         self._patch_w = None
         self._patch_ver = None
+        self.weights_source = None
+        if isinstance(image_tower, CLIPVisionConfig):
+            self.cfg_only = image_tower
+        else:
+            d = resolve_tower_dir(image_tower, self._search + (cache_dir,))
+            # delay_load in the reference reads only the config (clip_encoder.py:21-22)
+            self.cfg_only = read_clip_config(d) if d is not None else (
+                CLIPVisionConfig(**KNOWN_GEOMETRY[image_tower]) if image_tower in KNOWN_GEOMETRY else None)
         if not delay_load:
             self.load_model()
 
-    def load_model(self):
+    def load_model(self, search=()):
+        """clip_encoder.py:24-33: `CLIPVisionModel.from_pretrained(image_tower_name)`, frozen."""
         if self.is_loaded:
             return
-        self.image_tower = _CLIPVisionModel(self.cfg_only, self._device)
+        if isinstance(self.image_tower_name, CLIPVisionConfig):
+            self.image_tower = _CLIPVisionModel(self.cfg_only, self._device)      # explicit random-init architecture
+            self.weights_source = "random-init (CLIPVisionConfig object)"
+        else:
+            d = resolve_tower_dir(self.image_tower_name, tuple(search) + self._search + (self.cache_dir,))
+            if d is None:
+                raise FileNotFoundError(
+                    f"image tower {self.image_tower_name!r} is not a local checkpoint directory (config.json + "
+                    f"{' / '.join(_WEIGHT_FILES)}); hub names cannot be downloaded on this path and the tower is never "
+                    f"randomly initialised from a name — pass a directory, or load a checkpoint that carries "
+                    f"`model.image_tower.*` weights through from_pretrained")
+            self.load_from_dir(d)
         self.image_tower.requires_grad_(False)               # clip_encoder.py:31
+        self.is_loaded = True
+
+    def load_from_dir(self, d):
+        import os
+        from ...checkpoint import _read
+        f = next((os.path.join(d, n) for n in _WEIGHT_FILES if os.path.exists(os.path.join(d, n))), None)
+        if f is None:
+            raise FileNotFoundError(f"no {' / '.join(_WEIGHT_FILES)} under {d}")
+        self.cfg_only = read_clip_config(d)
+        self.load_from_state(_read(f), source=f)
+
+    def load_from_state(self, sd, source="state dict", heads=None):
+        """Build the tower (geometry from `cfg_only`, else from the tensor shapes) and copy `sd` into it; every tensor of
+        the layers that are executed must be present with the right shape."""
+        sd = normalise_clip_keys(sd)
+        if self.cfg_only is None:
+            self.cfg_only = geometry_from_state(sd, heads)
+        tower = _CLIPVisionModel(self.cfg_only, self._device)
+        own = tower.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"image tower weights from {source}: missing {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        with torch.no_grad():
+            for k, t in own.items():
+                if tuple(sd[k].shape) != tuple(t.shape):
+                    raise ValueError(f"{k}: {tuple(sd[k].shape)} in {source} != {tuple(t.shape)} of the configured geometry")
+                t.copy_(sd[k].to(device=t.device, dtype=t.dtype))
+        self.image_tower = tower
+        self.image_tower.requires_grad_(False)
+        self.weights_source = str(source)
         self.is_loaded = True
 
     @property
@@ -130,7 +257,7 @@ class CLIPVisionTower(nn.Module):
 
     @property
     def device(self):
-        return self.image_tower.vision_model.pre_layrnorm.weight.device
+        return self.image_tower.vision_model.pre_layrnorm.weight.device if self.is_loaded else torch.device(self._device)
 
     def _n_layers_run(self):
         L = self.cfg_only.num_hidden_layers
@@ -155,6 +282,9 @@ class CLIPVisionTower(nn.Module):
         GEMM's batch stride; `select_patches()` gives the explicit [B, P, D] tensor."""
         if self.select_feature != "patch":
             raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        if not self.is_loaded:
+            raise RuntimeError(f"image tower {self.image_tower_name!r} has no weights yet: call load_model() "
+                               f"(initialize_vision_modules) or from_pretrained first")
         c = self.cfg_only
         vm = self.image_tower.vision_model
         B = images.shape[0]

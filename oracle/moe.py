@@ -65,13 +65,14 @@ def top2gating(logits, capacity_factor, min_capacity, noise=None, forced=None):
     return l_aux, combine, dispatch, exp_counts
 
 
-def top1gating(logits, capacity_factor, min_capacity, rts_noise=None):
+def top1gating(logits, capacity_factor, min_capacity, rts_noise=None, forced=None):
     """sharded_moe.top1gating with noisy_gate_policy=None, drop_tokens=True.  rts_noise [S,E] uniform
-    noise for random token selection (use_rts=True); None -> token order (use_rts=False)."""
+    noise for random token selection (use_rts=True); None -> token order (use_rts=False).
+    forced: idx1 test hook (bf16-twin noise floors reuse the fp32 run's picks), not part of DeepSpeed."""
     S, E = logits.shape
     gates = F.softmax(logits, dim=1)
     C = capacity(S, E, capacity_factor, min_capacity)
-    idx1 = torch.argmax(gates, dim=1)
+    idx1 = torch.argmax(gates, dim=1) if forced is None else forced
     mask1 = F.one_hot(idx1, num_classes=E)
     exp_counts = torch.sum(mask1, dim=0).detach()
     me = torch.mean(gates, dim=0)
@@ -133,7 +134,10 @@ class OracleMoE(nn.Module):
             i2 = torch.argmax(lw.masked_fill(F.one_hot(i1, g.shape[1]).bool(), float("-inf")), dim=1)
             self.last_picks = (i1, i2, g, lw)
         else:
-            l_aux, combine, dispatch, exp_counts = top1gating(logits, cf, self.min_capacity, self.rts_noise)
+            forced = self.forced.pop(0) if isinstance(self.forced, list) else self.forced
+            l_aux, combine, dispatch, exp_counts = top1gating(logits, cf, self.min_capacity, self.rts_noise,
+                                                              None if forced is None else forced[0])
+            self.last_picks = (torch.argmax(logits.detach(), dim=1), None, F.softmax(logits.detach(), dim=1), logits.detach())
         dispatched = torch.einsum("sec,sm->ecm", dispatch.type_as(x), x)
         outs = [e(dispatched[i]) for i, e in enumerate(self.deepspeed_moe.experts.deepspeed_experts)]
         expert_out = torch.stack(outs, dim=0)

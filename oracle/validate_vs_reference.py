@@ -463,6 +463,91 @@ def write_gpu_small():
     json.dump(meta, open(os.path.join(GOLD, "gpusmall_mimic.json"), "w"), indent=1)
 
 
+def write_ref_checkpoint(R):
+    """A checkpoint WRITTEN BY THE REFERENCE (VERDICT r02 missing #3): the imported `LlavaQwen2ForCausalLM` at the GPU-small
+    geometry (head_dim 64) is saved by its own `save_pretrained` — config.json + model.safetensors in the reference's key
+    layout (`model.mm_projector.image_spatial_proj.*`, `model.image_tower.image_tower.*`, `lm_head`, decoder layers) — next
+    to the tiny CLIP directory `CLIPVisionModel.save_pretrained` wrote (the directory `--image_tower` names), the adapter-only
+    `mm_projector.bin` as `safe_save_model_for_hf_trainer` writes it (train/align_train.py:623-631), and the reference's own
+    logits / labels / loss on a ragged batch.  tests/ load it through the product `from_pretrained` (GPU) and through the
+    name mapping alone (CPU).  Tensors + JSON only; weights are bf16-representable so the bf16 product path holds them exactly."""
+    from safetensors.torch import save_file
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    print("[reference-written checkpoint fixture]")
+    out_dir = os.path.join(GOLD, "ref_ckpt")
+    clip_name = "openai_clip_tiny"                           # the reference's builder wants "openai" in the path
+    os.makedirs(out_dir, exist_ok=True)
+    vc, _, tc = small_gpu_cfgs()
+    hc = CLIPVisionConfig(hidden_size=vc.hidden_size, intermediate_size=vc.intermediate_size,
+                          num_hidden_layers=vc.num_hidden_layers, num_attention_heads=vc.num_attention_heads,
+                          image_size=vc.image_size, patch_size=vc.patch_size, hidden_act="quick_gelu",
+                          layer_norm_eps=vc.layer_norm_eps)
+    torch.manual_seed(21)
+    hf = CLIPVisionModel(hc).eval()
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if "norm" in n_ and n_.endswith("weight"):
+                p_.fill_(1.0)
+            elif "norm" in n_ and n_.endswith("bias"):
+                p_.zero_()
+            else:
+                p_.copy_((0.05 * torch.randn(p_.shape)).to(torch.bfloat16).float())
+    hf.save_pretrained(os.path.join(out_dir, clip_name))
+    json.dump({"do_resize": False, "do_center_crop": False, "do_normalize": False, "image_processor_type": "CLIPImageProcessor"},
+              open(os.path.join(out_dir, clip_name, "preprocessor_config.json"), "w"))
+    cwd = os.getcwd()
+    os.chdir(out_dir)                                        # the tower is named RELATIVE to the checkpoint: portable fixture
+    try:
+        cfg = ref_qwen2_config(R, tc, "eager")
+        ref = R.lq.LlavaQwen2ForCausalLM(cfg)
+        margs = SimpleNamespace(image_tower=clip_name, video_tower=None, mm_vision_select_layer=-2,
+                                mm_vision_select_feature="patch", pretrain_mm_mlp_adapter=None,
+                                image_projector_type="mlp2x_gelu", video_projector_type="linear", video_global_proj=False,
+                                video_temproal_proj=False, video_spatial_proj=False)
+        ref.get_model().initialize_vision_modules(margs, fsdp=None)
+        g = torch.Generator().manual_seed(22)
+        with torch.no_grad():
+            for n_, p_ in ref.named_parameters():
+                if "image_tower" in n_:
+                    continue                                   # loaded by the reference from the CLIP directory
+                if "norm" in n_ and n_.endswith("weight"):
+                    p_.fill_(1.0)
+                else:
+                    p_.copy_((0.02 * torch.randn(p_.shape, generator=g)).to(torch.bfloat16).float())
+        ref.eval()
+        b = tiny_batch(seed=5, B=2, T=12, ragged=True)
+        b["images"] = b["images"].to(torch.bfloat16).float()
+        ro = ref(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"],
+                 images=list(b["images"]), return_dict=True)
+        for f in os.listdir("."):                              # regenerate from scratch
+            if f.endswith((".safetensors", ".json", ".bin")) and os.path.isfile(f):
+                os.remove(f)
+        try:
+            ref.config.mm_image_tower = clip_name
+            ref.save_pretrained(".", safe_serialization=True)
+            how = "reference model.save_pretrained()"
+        except Exception as e:                                 # transformers 5.x vs the 4.37-era vendored classes
+            print(f"  (save_pretrained failed: {type(e).__name__}: {str(e)[:100]} -> state_dict()/config.to_dict() dump)")
+            save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, "model.safetensors", metadata={"format": "pt"})
+            json.dump(ref.config.to_dict(), open("config.json", "w"), indent=1, default=str)
+            how = "reference state_dict() + config.to_dict()"
+        # safe_save_model_for_hf_trainer(tune_mm_mlp_adapter=True): get_mm_adapter_state_maybe_zero_3(named_parameters, ['mm_projector'])
+        adapter = {k: v.detach().cpu().clone() for k, v in ref.named_parameters() if "mm_projector" in k}
+        torch.save(adapter, "mm_projector.bin")
+        live = torch.zeros_like(ro.labels, dtype=torch.bool)
+        for i, m in enumerate(b["attention_mask"]):
+            live[i, :int(m.sum()) - 1 + 4] = True
+        save_file({"input_ids": b["input_ids"], "attention_mask": b["attention_mask"].to(torch.int64), "labels": b["labels"],
+                   "images": b["images"], "ref_logits": ro.logits.detach().contiguous(), "ref_labels": ro.labels,
+                   "ref_loss": ro.loss.detach().reshape(1), "live": live.to(torch.int64)}, "expected.safetensors")
+        json.dump({"written_by": how, "reference_class": "llavamod.model.language_model.llava_qwen2.LlavaQwen2ForCausalLM",
+                   "image_tower": clip_name, "transformers": transformers.__version__,
+                   "state_dict_keys": sorted(ref.state_dict().keys())}, open("MANIFEST.json", "w"), indent=1)
+        print(f"  wrote {out_dir} via {how}: {sorted(os.listdir('.'))}")
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -478,6 +563,7 @@ def main():
     known = check_trainer_fns(R)
     if not a.check:
         write_golden(known, ref_teacher)
+        write_ref_checkpoint(R)
     print("ALL REFERENCE CHECKS PASSED")
 
 

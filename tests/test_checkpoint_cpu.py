@@ -82,3 +82,107 @@ def test_dense_checkpoint_upcycles_and_key_dialects(tmp_path):
     save_file(bad, str(tmp_path / "bad.safetensors"))
     with pytest.raises(ValueError):
         load_checkpoint(other, str(tmp_path / "bad.safetensors"))
+
+
+# ---- the fixture WRITTEN BY THE REFERENCE (oracle/validate_vs_reference.py::write_ref_checkpoint) ------------------------
+REF_CKPT = os.path.join(ROOT, "tests", "golden", "ref_ckpt")
+
+
+def test_from_pretrained_reads_the_reference_written_checkpoint():
+    """`from_pretrained` on a directory the imported reference `LlavaQwen2ForCausalLM` wrote (its state_dict() + its config,
+    the CLIP directory `CLIPVisionModel.save_pretrained` wrote beside it): every decoder / projector tensor arrives under the
+    reference's name, the tower comes from ITS directory (clip_encoder.py:24-33), nothing is missing or left over."""
+    import json
+    from safetensors.torch import load_file
+    from llavamod.model import LlavaQwen2ForCausalLM
+    man = json.load(open(os.path.join(REF_CKPT, "MANIFEST.json")))
+    assert man["reference_class"].endswith("LlavaQwen2ForCausalLM")
+    model = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, attn_implementation="sdpa", torch_dtype=torch.bfloat16, device="cpu")
+    tower = model.get_image_tower()
+    assert tower.is_loaded and tower.weights_source.endswith(os.path.join("openai_clip_tiny", "model.safetensors"))
+    assert (tower.hidden_size, tower.num_patches, tower.config.num_attention_heads) == (64, 4, 1)
+    ref = load_file(os.path.join(REF_CKPT, "model.safetensors"))
+    clip = load_file(os.path.join(REF_CKPT, "openai_clip_tiny", "model.safetensors"))
+    own = model.state_dict()
+    seen = set()
+    for k, v in ref.items():
+        if k.endswith("inv_freq") or k.endswith("position_ids"):
+            continue
+        kk = k if "image_tower" not in k else k.replace("image_tower.image_tower.", "image_tower.image_tower.vision_model.") \
+            if "vision_model." not in k else k
+        assert kk in own, k                                  # every reference name exists in this module tree
+        assert torch.equal(own[kk].float(), v.float()), k     # bf16-representable values: exact
+        seen.add(kk)
+    assert seen == set(own), sorted(set(own) - seen)[:5]
+    # the tower tensors equal the CLIP directory's (the reference's state dict holds the same values: it loaded them from there)
+    for k, v in clip.items():
+        if k.endswith("position_ids"):
+            continue
+        kk = "model.image_tower.image_tower." + (k if k.startswith("vision_model.") else "vision_model." + k)
+        assert torch.equal(own[kk].float(), v.float()), k
+    assert not any(p.requires_grad for p in tower.parameters())
+
+
+def test_adapter_only_save_matches_the_reference_file(tmp_path):
+    """`save_mm_adapter` writes what the reference's `safe_save_model_for_hf_trainer(tune_mm_mlp_adapter)` wrote into the
+    fixture (same key set, same tensors), and `initialize_vision_modules(pretrain_mm_mlp_adapter=...)` reads it back."""
+    from types import SimpleNamespace
+    from llavamod.model import LlavaQwen2ForCausalLM
+    model = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, device="cpu")
+    path = model.save_mm_adapter(str(tmp_path))
+    mine, ref = torch.load(path), torch.load(os.path.join(REF_CKPT, "mm_projector.bin"))
+    assert set(mine) == set(ref) == {"model.mm_projector.image_spatial_proj.0.weight", "model.mm_projector.image_spatial_proj.0.bias",
+                                    "model.mm_projector.image_spatial_proj.2.weight", "model.mm_projector.image_spatial_proj.2.bias"}
+    for k in ref:
+        assert torch.equal(mine[k].float(), ref[k].float()), k
+    with torch.no_grad():
+        for p in model.get_model().mm_projector.parameters():
+            p.zero_()
+    margs = SimpleNamespace(image_tower=os.path.join(REF_CKPT, "openai_clip_tiny"), mm_vision_select_layer=-2,
+                            mm_vision_select_feature="patch", image_projector_type="mlp2x_gelu",
+                            pretrain_mm_mlp_adapter=os.path.join(REF_CKPT, "mm_projector.bin"))
+    model.get_model().initialize_vision_modules(margs)
+    sd = model.state_dict()
+    for k in ref:
+        assert torch.equal(sd[k].float(), ref[k].float()), k
+    assert all(p.requires_grad for p in model.get_model().mm_projector.parameters())
+
+
+def test_named_tower_never_random_initialises(tmp_path):
+    """A tower given by NAME loads from a local directory or from the main checkpoint's own tensors — otherwise it raises
+    (VERDICT r02 missing #2: `CLIPVisionModel.from_pretrained(self.image_tower_name)`, clip_encoder.py:24-33)."""
+    import json
+    import shutil
+    from types import SimpleNamespace
+    from llavamod.model import LlavaQwen2ForCausalLM
+    from llavamod.model.multimodal_encoder.builder import build_image_tower
+    args = SimpleNamespace(image_tower="openai/clip-vit-large-patch14-336", mm_vision_select_layer=-2)
+    with pytest.raises(FileNotFoundError):
+        build_image_tower(args, device="cpu")
+    lazy = build_image_tower(args, device="cpu", delay_load=True)       # config only, like the reference's delay_load
+    assert not lazy.is_loaded and lazy.num_patches == 576 and lazy.hidden_size == 1024
+    with pytest.raises(RuntimeError):
+        lazy(torch.zeros(1, 3, 336, 336))
+    # (1) hub name in config.json, no tower tensors in the checkpoint: from_pretrained raises
+    work = tmp_path / "hub_no_keys"
+    shutil.copytree(REF_CKPT, work)
+    shutil.rmtree(work / "openai_clip_tiny")
+    cfg = json.load(open(work / "config.json"))
+    cfg["mm_image_tower"] = "openai/clip-vit-base-patch32"
+    json.dump(cfg, open(work / "config.json", "w"))
+    from safetensors.torch import load_file, save_file
+    sd = load_file(str(work / "model.safetensors"))
+    save_file({k: v for k, v in sd.items() if "image_tower" not in k}, str(work / "model.safetensors"))
+    with pytest.raises(FileNotFoundError):
+        LlavaQwen2ForCausalLM.from_pretrained(str(work), device="cpu")
+    # (2) unknown hub name, but the checkpoint carries `model.image_tower.*`: geometry from the shapes, weights from the file
+    cfg["mm_image_tower"] = "someone/openai-clip-like"
+    json.dump(cfg, open(work / "config.json", "w"))
+    save_file(sd, str(work / "model.safetensors"))
+    m = LlavaQwen2ForCausalLM.from_pretrained(str(work), device="cpu")
+    t = m.get_image_tower()
+    assert t.is_loaded and "model.image_tower.image_tower." in t.weights_source
+    assert (t.hidden_size, t.config.num_hidden_layers, t.config.image_size, t.config.patch_size) == (64, 3, 28, 14)
+    ref = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, device="cpu")
+    for (ka, va), (kb, vb) in zip(m.state_dict().items(), ref.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka

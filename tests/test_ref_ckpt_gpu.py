@@ -1,0 +1,62 @@
+"""`from_pretrained` on the checkpoint the REFERENCE wrote (tests/golden/ref_ckpt, produced by
+oracle/validate_vs_reference.py::write_ref_checkpoint from the imported `LlavaQwen2ForCausalLM`) reproduces the
+reference's own logits / labels / loss on the GPU — SURVEY §8 f3: real LLaVA-MoD weights drop in by name, the CLIP tower
+arrives from the directory `--image_tower` names (clip_encoder.py:24-33)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "llava-mod_amd"))
+
+import _util as U  # noqa: E402
+from oracle.decoder import DecoderConfig  # noqa: E402
+from oracle.llava import LlavaOracle  # noqa: E402
+from oracle.vision import VisionConfig  # noqa: E402
+
+REF_CKPT = os.path.join(ROOT, "tests", "golden", "ref_ckpt")
+
+
+def test_reference_written_checkpoint_reproduces_reference_logits():
+    from safetensors.torch import load_file
+    from llavamod.model import LlavaQwen2ForCausalLM
+    exp = load_file(os.path.join(REF_CKPT, "expected.safetensors"))
+    model = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, attn_implementation="flash_attention_2",
+                                                  torch_dtype=torch.bfloat16, device="cuda")
+    assert model.get_image_tower().is_loaded and "openai_clip_tiny" in model.get_image_tower().weights_source
+    model.eval()
+    batch = dict(input_ids=exp["input_ids"], attention_mask=exp["attention_mask"].bool(), labels=exp["labels"],
+                 images=exp["images"].to("cuda").to(torch.bfloat16))
+    with torch.no_grad():
+        out = model(**batch)
+    assert torch.equal(out.labels.cpu(), exp["ref_labels"])
+    live = exp["live"].bool()
+    ref = exp["ref_logits"]
+    # noise floor: the oracle carrying the product model's weights (it must reproduce the reference's logits in fp32 —
+    # the pin of the oracle to this fixture on the GPU box) against its own bf16 twin
+    vc = VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=1,
+                      image_size=28, patch_size=14, select_layer=-2)
+    tc = DecoderConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=2)
+    oracle = LlavaOracle(tc, vc, moe=False)
+    inv = {U.oracle_to_hip_key(k): k for k in oracle.state_dict()}
+    oracle.load_state_dict({inv[k]: v.float().cpu() for k, v in model.state_dict().items()})
+    oracle.eval()
+    ob = dict(input_ids=exp["input_ids"], attention_mask=exp["attention_mask"].bool(), labels=exp["labels"], images=exp["images"])
+    with torch.no_grad():
+        oo = oracle(**ob)
+        twin = oracle.to(torch.bfloat16)
+        tw = twin(**dict(ob, images=ob["images"].to(torch.bfloat16)))
+    assert (oo.logits[live] - ref[live]).abs().max().item() <= 2e-5 * ref[live].abs().max().item() + 2e-6
+    assert abs(float(oo.loss) - float(exp["ref_loss"])) <= 2e-5 * abs(float(exp["ref_loss"]))
+    err = (out.logits.float().cpu()[live] - ref[live]).abs().max().item()
+    floor = (tw.logits.float()[live] - ref[live]).abs().max().item()
+    print(f"reference-written checkpoint: logits max error {err:.3e}, bf16 floor {floor:.3e}, scale {ref[live].abs().max().item():.3e}")
+    assert err <= 2.0 * floor, (err, floor)
+    assert abs(float(out.loss) - float(exp["ref_loss"])) <= 1e-3 * abs(float(exp["ref_loss"]))

@@ -5,9 +5,9 @@ Tolerance (north_star: "within 1e-3 bf16 tolerance"): the GPU path keeps activat
 where the reference's bf16 run does, the oracle computes in fp32 on the same bf16-rounded weights, so
 the residual is bf16 activation rounding.  Loss scalars and sequence log-probabilities must agree to
 1e-3 relative.  Quantities whose natural scale is not their own magnitude — gradients, DPO loss /
-reward (differences of ~-150 sums), materialised log-probabilities — are held to 2x their measured
+reward (differences of ~-150 sums), materialised log-probabilities, logits — are held to 2x their measured
 bf16 NOISE FLOOR: the oracle's own bf16 twin (`_bf16_twin`) against the fp32 oracle, same inputs, same
-routing.  Golden small case: logits to 1e-3 of their scale + 2 bf16 ulp, gradients 3e-2 of the max.
+routing (`_twin_run`, `_check_grads_floor`).  No flat gradient / logit bound is left in this file.
 """
 import os
 import sys
@@ -54,21 +54,6 @@ def _froerr(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def _check_grads(hgrads, ograds, tol_max, tol_fro):
-    """Dense tensors: max-abs error relative to the tensor's max.  Expert / router tensors: relative
-    Frobenius error — the bf16 path and the fp32 oracle can break a near-tied router argmax differently
-    for a token or two (expected ~0.4% of decisions), which moves single expert rows but not the bulk."""
-    for n, ref in ograds.items():
-        if ref.abs().max() == 0:
-            continue
-        if "deepspeed_moe" in n:
-            e = _froerr(hgrads[n], ref)
-            assert e <= tol_fro, (n, "fro", e)
-        else:
-            e = U.relerr(hgrads[n], ref)
-            assert e <= tol_max, (n, "max", e)
-
-
 def _grads_of(student):
     return {n: p.main_grad for n, p in student.named_parameters() if p.requires_grad and getattr(p, "main_grad", None) is not None}
 
@@ -91,12 +76,21 @@ def test_golden_small_mimic_step(tag):
         so, to = student(**batch), teacher(**batch)
     assert torch.equal(so.labels.cpu(), g[f"{tag}.labels"])
     live = (batch["attention_mask"].sum(1) - 1 + 4)
-    for name, out in (("student", so), ("teacher", to)):
+    # bf16 noise floors of this very case: the oracle (which must reproduce the committed golden values) and its bf16 twin
+    o_student, o_teacher = _oracle_pair_from(ssd, tsd, sc, tc, vc)
+    ob = {k: g[f"{tag}.batch." + k] for k in ("input_ids", "attention_mask", "labels", "images")}
+    ob["attention_mask"] = ob["attention_mask"].bool()
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None])
+    _, logs_o, s_o, t_o = mimic_step(o_student, o_teacher, ob, loss_type=meta["loss_type"], align_vocab=512)
+    assert torch.allclose(s_o.logits, g[f"{tag}.student_logits"], atol=1e-5) and torch.allclose(t_o.logits, g[f"{tag}.teacher_logits"], atol=1e-5)
+    fgrads, _, s_f, t_f = _twin_run(o_student, o_teacher, ob, meta["loss_type"], 512, [None])
+    for name, out, twin in (("student", so, s_f), ("teacher", to, t_f)):
         ref = g[f"{tag}.{name}_logits"]
         for b in range(ref.shape[0]):
             n = int(live[b])
             d = (out.logits[b, :n].float().cpu() - ref[b, :n]).abs().max().item()
-            assert d <= 1e-3 * ref.abs().max().item() + 2 ** -7 * ref[b, :n].abs().max().item(), (name, b, d)
+            floor = (twin.logits[b, :n].float() - ref[b, :n]).abs().max().item()
+            assert d <= 2.0 * floor, (name, b, d, floor)
     # (2) trainer API: fused loss step
     tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
                                                                loss_type=meta["loss_type"], moe_loss_enable=True))(),
@@ -109,16 +103,10 @@ def test_golden_small_mimic_step(tag):
         assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
     # (3) gradients of every trainable tensor
     grads = _grads_of(student)
-    worst = 0.0
-    for k, ref in g.items():
-        if not k.startswith(f"{tag}.grad."):
-            continue
-        name = U.oracle_to_hip_key(k[len(f"{tag}.grad."):])
-        assert name in grads, name
-        e = U.relerr(grads[name], ref)
-        worst = max(worst, e)
-        assert e <= 3e-2, (name, e)
-    assert len(grads) > 10 and worst > 0
+    golden = {U.oracle_to_hip_key(k[len(f"{tag}.grad."):]): ref for k, ref in g.items() if k.startswith(f"{tag}.grad.")}
+    assert set(golden) <= set(grads) and len(golden) > 10
+    worst = _check_grads_floor(grads, golden, fgrads, f"golden small ({tag})")
+    assert worst[0] > 0
 
 
 def _bf16_twin(model):
@@ -137,6 +125,41 @@ def _bf16_twin(model):
 
 def _bf16_batch(batch):
     return {k: (v.to(torch.bfloat16) if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+
+
+def _twin_run(o_student, o_teacher, ob, loss_type, align_vocab, noises):
+    """The bf16 twin of an oracle pair stepped on the same batch with the fp32 run's routing picks forced (the floor is a
+    rounding question; routing is gated separately).  Call AFTER the fp32 `mimic_step` (its `last_picks` are read).
+    Returns (twin gradients by product name, twin logs, twin student output, twin teacher output)."""
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(noises)
+    for om, ot in zip(_oracle_moes(o_student), _oracle_moes(tw_s)):
+        if om.last_picks is not None:
+            ot.forced = (om.last_picks[0], om.last_picks[1])
+    _, logs_f, s_out, t_out = mimic_step(tw_s, tw_t, _bf16_batch(ob), loss_type=loss_type, align_vocab=align_vocab)
+    fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
+    return fgrads, logs_f, s_out, t_out
+
+
+def _check_grads_floor(hgrads, ograds, fgrads, what=""):
+    """Every gradient within 2x its own bf16 noise floor (5e-3 of the tensor's max where the floor is below that: the
+    GPU path's MFMA accumulation order differs from the twin's)."""
+    worst = (0.0, None, 0.0)
+    for n, ref in ograds.items():
+        if ref.abs().max() == 0:
+            continue
+        e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
+        assert e <= max(2.0 * floor, 5e-3), (what, n, e, floor)
+        worst = max(worst, (e, n, floor))
+    print(f"{what}: worst gradient error {worst[0]:.4f} ({worst[1]}), its bf16 floor {worst[2]:.4f}")
+    return worst
+
+
+def _oracle_pair_from(ssd, tsd, sc, tc, vc):
+    o_student, o_teacher = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
+    o_student.load_state_dict(ssd); o_teacher.load_state_dict(tsd)
+    freeze_like_d2s(o_student)
+    return o_student, o_teacher
 
 
 def _seeded_pair(seed, sc, tc, vc):
@@ -364,7 +387,8 @@ def test_finetune_student_and_top1_step():
         got, exp = float(outs[k].detach()), float(logs_o[k].detach())
         assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
     ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
-    _check_grads(_grads_of(s1), ograds, 3e-2, 5e-2)
+    fgrads, _, _, _ = _twin_run(o_student, o_teacher, ob, "kd_lm", 512, [None])
+    _check_grads_floor(_grads_of(s1), ograds, fgrads, "top-1 student")
 
 
 @pytest.mark.parametrize("everything", [False, True])
@@ -408,7 +432,8 @@ def test_trainable_norms_and_embedding_step(everything):
     assert set(ograds) == set(hgrads), sorted(set(ograds) ^ set(hgrads))[:8]
     new = [n for n in ograds if any(n.endswith(e) for e in extra)]
     assert len(new) == 2 * sc.num_hidden_layers + 2
-    _check_grads(hgrads, ograds, 3e-2, 5e-2)
+    fgrads, _, _, _ = _twin_run(o_student, o_teacher, ob, "kd_lm", 512, [None])
+    _check_grads_floor(hgrads, ograds, fgrads, f"trainable norms/embedding (everything={everything})")
     # second backward accumulates (gradient accumulation contract of main_grad)
     before = {n: hgrads[n].clone() for n in new}
     loss2 = tr.compute_loss(student, _batch_from(g, "ragged_kdlm"))
