@@ -133,3 +133,27 @@ def load_checkpoint(model, path, strict=True, ignore_prefixes=(), state=None):
     # optimizers holding fp32 masters must be told (HipAdamW.resync_master()); trainers re-check tower sharing
     model._weights_epoch = getattr(model, "_weights_epoch", 0) + 1
     return missing, unexpected
+
+
+def save_optimizer(opt, out_dir):
+    """`HipAdamW.state_dict()` of THIS rank -> `optimizer_rank{r}_of{w}.pt` (atomic).  With the ZeRO-2 style optimizer the
+    fp32 master / m / v exist only as per-rank shards, so every rank saves its own file (DeepSpeed's
+    `zero_pp_rank_*_optim_states.pt` convention)."""
+    os.makedirs(out_dir, exist_ok=True)
+    st = opt.state_dict()
+    path = os.path.join(out_dir, f"optimizer_rank{st['rank']}_of{st['world']}.pt")
+    torch.save(st, path + ".tmp")
+    os.replace(path + ".tmp", path)
+    return path
+
+
+def load_optimizer(opt, in_dir):
+    """Inverse of `save_optimizer` for this rank; raises if the shard layout differs (exact resume needs the same world
+    size / ZeRO-2 setting / trainable set)."""
+    world = opt.dp.world if opt.dp is not None else 1
+    rank = opt.dp.rank if opt.dp is not None else 0
+    path = os.path.join(in_dir, f"optimizer_rank{rank}_of{world}.pt")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: no optimizer state for rank {rank} of {world}")
+    opt.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    return path

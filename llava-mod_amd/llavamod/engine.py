@@ -485,6 +485,33 @@ class HipAdamW:
         for h in handles:
             h.wait()
 
+    # ---- exact resume ------------------------------------------------------------------------------------------------
+    def _layout(self):
+        return [(kind, lo, hi, soff) for kind, _, lo, hi, soff, _, _ in self.items]
+
+    def state_dict(self):
+        """This rank's optimizer state: fp32 master / m / v of the chunks it owns (all of them without ZeRO-2), the step
+        count, the shard layout they belong to, and the MoE layers' gating-noise counters (so a resumed run continues the
+        noise stream).  With ZeRO-2 every rank saves its own (`checkpoint.save_optimizer` names the file by rank)."""
+        self.sync()
+        moes = [m for m in self.gb.model.modules() if hasattr(m, "noise_state")]
+        return {"step_count": self.step_count, "master": self.master.detach().cpu(), "m": self.m.detach().cpu(),
+                "v": self.v.detach().cpu(), "layout": self._layout(), "n_state": self.n_state,
+                "world": self.dp.world if self.dp is not None else 1, "rank": self.dp.rank if self.dp is not None else 0,
+                "zero2": bool(self.dp is not None and self.dp.zero2), "moe_noise": [m.noise_state() for m in moes]}
+
+    def load_state_dict(self, st):
+        if st["n_state"] != self.n_state or [tuple(x) for x in st["layout"]] != self._layout():
+            raise ValueError("optimizer state was saved under a different span / shard layout (world size, ZeRO-2 setting "
+                             "or trainable set changed): it cannot be resumed exactly")
+        self.step_count = int(st["step_count"])
+        for name in ("master", "m", "v"):
+            getattr(self, name).copy_(st[name].to(getattr(self, name).device))
+        moes = [m for m in self.gb.model.modules() if hasattr(m, "noise_state")]
+        for m, ns in zip(moes, st.get("moe_noise", [])):
+            m.load_noise_state(ns)
+        self._weights_epoch = getattr(self.gb.model, "_weights_epoch", 0)    # masters come from the file, not the model
+
     def sync(self):
         """Make the current stream wait for an overlapped step (before reading weights outside a forward)."""
         if self._stream is not None:

@@ -153,6 +153,11 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             if packed:
                 from ..llava_arch import pack_loss_plan
                 info.plan = pack_loss_plan(info.plan, plan)
+            elif getattr(info.plan, "is_packed", False):
+                # e.g. a teacher that ran unpadded handing its plan to a student that runs padded: the row indices would
+                # address packed rows in a padded buffer
+                raise ValueError("loss plan is in packed (unpadded) coordinates but this model executes padded: set `unpad` "
+                                 "identically on the teacher and the student")
             info.plan.pregathered = True
             out_rows, inv_rows = info.plan.row_idx, info.plan.inv_row_idx
         if packed:
@@ -182,7 +187,12 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
     @torch.no_grad()
     def _prefill(self, input_ids, attention_mask, images, max_new_tokens):
         """Splice + full forward storing K/V; returns (cache, bf16 logits [B, V] of each sample's LAST valid position)."""
-        _, _, am, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None, images)
+        unpad, self.unpad = getattr(self, "unpad", False), False       # the KV cache is laid out per padded sample
+        try:
+            _, _, am, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None, images)
+        finally:
+            self.unpad = unpad
+        plan = self._plan
         dev = self.model.embed_tokens.weight.device
         if embeds is None:
             B, S = input_ids.shape
@@ -190,7 +200,20 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             embeds = K.gather_rows(self.model.embed_tokens.weight, None, idx, self.model.embed_tokens.weight.shape[1]).view(B, S, -1)
             am = attention_mask
         B, S, H = embeds.shape
-        lens = (am.to(device=dev).to(torch.int32).sum(1) if am is not None else torch.full((B,), S, device=dev)).to(torch.int32)
+        if embeds is not None and plan is not None:
+            # spliced batch: the plan knows every sample's real length (also when no attention_mask was given but the
+            # samples splice to different lengths)
+            lens = torch.from_numpy(plan.lens_np.astype("int32")).to(dev)
+        elif am is not None:
+            amd = am.to(device=dev).to(torch.int32)
+            lens = amd.sum(1).to(torch.int32)
+            # the cache and the last-token row are addressed as b*S + len-1: RIGHT padding only (the reference's
+            # `padding_side="right"`, align_train.py:366).  A left-padded mask would silently read the wrong rows.
+            if bool((amd[:, 1:] > amd[:, :-1]).any()):
+                raise ValueError("generate/use_cache expects RIGHT-padded prompts (attention_mask must be non-increasing along "
+                                 "the sequence); left padding is not supported on this path")
+        else:
+            lens = torch.full((B,), S, device=dev, dtype=torch.int32)
         seqlens = lens.contiguous() if bool((lens != S).any()) else None
         cfg = self.config
         cache = KVCache(cfg.num_hidden_layers, B, S + max_new_tokens, cfg.num_key_value_heads * cfg.head_dim, dev)

@@ -74,6 +74,7 @@ class LLaVAMoDQwen2ForCausalLM(_CausalLMBase):
             self.model.layers[li].mlp = MoE(self.config.hidden_size, expert=dense, num_experts=n_exp, ep_size=ep_size,
                                             k=k, capacity_factor=cf, eval_capacity_factor=ecf, min_capacity=min_cap,
                                             use_residual=use_residual)
+            self.model.layers[li].mlp._layer_id = li + 1         # noise stream keyed by position in the model
 
     def initialize_moe_modules(self, model_args):
         """llava_qwen2_moe.py:475-561: record the knobs, freeze by substring BEFORE conversion, choose the

@@ -156,6 +156,9 @@ def pack_loss_plan(lp, splice):
         return lp
     to_packed = splice.to_packed
     rows = to_packed[lp.row_idx.long()]
+    if rows.numel() and bool((rows < 0).any()):                # one read-back, on the opt-in unpadded path only
+        raise ValueError("a loss row is a padding position (distill_all_tokens distils pads too): the unpadded execution "
+                         "(`model.unpad`) has no such rows — run this batch padded")
     out = SimpleNamespace(**vars(lp))
     out.is_packed = True
     out.row_idx = rows.contiguous()

@@ -5,7 +5,8 @@ read at :547; router parameter name contains `wg`, matched by substring at :501-
 Semantics restate DeepSpeed 0.9.5 (top-1/top-2 gating with capacity, token-order slots, drops,
 renormalised top-2 weights, l_aux) but execute sparsely on HIP kernels: see llavamod.ops.MoEBlock.
 Expert parallelism: `ep_size` > 1 shards the experts over ranks and exchanges capacity slabs with
-an RCCL all-to-all (llavamod.engine.ExpertParallel); ep_size == 1 is the reference shells' setting.
+RCCL all-to-alls (`MoE._forward_expert_parallel` below over `llavamod.engine.expert_parallel_group`; gradients of the
+sharded experts are reduced over `engine.expert_data_parallel_group`); ep_size == 1 is the reference shells' setting.
 """
 import copy
 import math
@@ -75,11 +76,24 @@ class MoE(nn.Module):
         # MoE path.  gate_noise: explicit [T, E] noise for the next forward instead (parity tests feed the oracle the same).
         self.gate_noise = None
         self.deterministic = False  # True: no noise at all (top-2: plain 2nd argmax; top-1: token-order selection)
+        # Noise stream identity: (torch seed, layer id, call counter).  The layer id is the layer's INDEX in its model
+        # (`_build_moe_layers` sets it; a layer built on its own takes a construction counter), so it does not depend on
+        # what else the process built before; training and eval forwards draw from separate streams with separate
+        # counters (eval / generate calls between train steps do not shift the training noise); the counters are saved
+        # and restored with the optimizer state (`noise_state`), so a resumed run continues the stream instead of
+        # replaying step 0's noise.
         MoE._LAYERS[0] += 1
         self._layer_id = MoE._LAYERS[0]
         self._calls = 0
+        self._eval_calls = 0
 
     _LAYERS = [0]
+
+    def noise_state(self):
+        return {"layer_id": self._layer_id, "calls": self._calls, "eval_calls": self._eval_calls}
+
+    def load_noise_state(self, st):
+        self._calls, self._eval_calls = int(st["calls"]), int(st.get("eval_calls", 0))
 
     def _noise(self, T, device):
         """(explicit noise tensor or None, Philox seed or None, counter offset) of this forward."""
@@ -88,8 +102,13 @@ class MoE(nn.Module):
         if self.gate_noise is not None:
             return self.gate_noise.to(device=device, dtype=torch.float32).contiguous(), None, 0
         seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._layer_id * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
-        off = self._calls * (1 << 24)            # a fresh counter range per call (T < 2^24 tokens)
-        self._calls += 1
+        if self.training:
+            off = self._calls * (1 << 24)        # a fresh counter range per call (T < 2^24 tokens)
+            self._calls += 1
+        else:                                    # DeepSpeed's gate draws noise in eval too: its own stream
+            seed ^= 0xA5A5A5A55A5A5A5A
+            off = self._eval_calls * (1 << 24)
+            self._eval_calls += 1
         return None, seed, off
 
     def capacity(self, T):
@@ -125,9 +144,18 @@ class MoE(nn.Module):
         return out.reshape(shp), l_aux.reshape(()), counts
 
     def _forward_expert_parallel(self, x, spec, noise):
-        """MOELayer.forward with its two all-to-alls (deepspeed.moe.sharded_moe): route locally over all E
-        experts, exchange [ep, E_local*C, H] capacity slabs, run the local experts on every source rank's
-        slab, exchange back, combine."""
+        """MOELayer.forward with its two all-to-alls (deepspeed.moe.sharded_moe): route locally over all E experts,
+        exchange the capacity slabs, run the local experts on every source rank's slab, exchange back, combine.
+
+        What travels (`ep_live_rows`, default): only the LIVE rows of each slab.  The ranks first exchange their per-expert
+        live counts (`slots_used`, ep*E_local ints), then one unequal-split `all_to_all_single` carries the packed live
+        rows each way.  With top-2 of E experts at capacity factor 1.5 a slab holds C = 3T/E slots but on average 2T/E
+        routed tokens, so about a third of DeepSpeed's [E, C, H] bytes were dead slots; with imbalanced routers the busiest
+        expert still ships at most C rows.  Cost: one host read-back of 2*E counts per MoE layer per direction of the step
+        (DeepSpeed's own gate syncs `exp_counts` to the host at the same point).  `ep_live_rows = False` (or
+        LMOD_EP_FULL_SLABS=1) ships whole [E_local*C, H] slabs like the reference; results are identical
+        (tests/test_dp_gloo.py, tests/test_moe_ep_gpu.py)."""
+        import os
         import torch.distributed as dist
         H = x.shape[1]
         ep, El = self.ep_size, self.num_local_experts
@@ -139,14 +167,28 @@ class MoE(nn.Module):
         disp, w1, w2, l_aux, counts = ops.MoERoute.apply(x, spec, noise, *router_params)
         st = spec.last_state
         C = st.C
-        recv = ops.AllToAll.apply(disp.view(ep, El * C, H), group)
         rows = st.slots_used.view(ep, El)
         if group is not None:          # live rows of each incoming slab (tiny int exchange)
             rr = torch.empty_like(rows)
             dist.all_to_all_single(rr, rows.contiguous(), group=group)
-            rows = rr
+        else:
+            rr = rows
         expert_params = [q for q in self.deepspeed_moe.experts.parameters() if q.requires_grad]
-        y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rows.contiguous(), *expert_params)
-        back = ops.AllToAll.apply(y.view(ep, El * C, H), group)
-        out = ops.MoECombine.apply(back.reshape(self.num_experts * C, H), w1, w2, st)
+        live = getattr(self, "ep_live_rows", True) and os.environ.get("LMOD_EP_FULL_SLABS") != "1"
+        if not live:
+            recv = ops.AllToAll.apply(disp.view(ep, El * C, H), group)
+            y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rr.contiguous(), *expert_params)
+            back = ops.AllToAll.apply(y.view(ep, El * C, H), group)
+            return ops.MoECombine.apply(back.reshape(self.num_experts * C, H), w1, w2, st), l_aux, counts
+        host = torch.stack([rows.reshape(-1), rr.reshape(-1)]).cpu().numpy()      # the one host sync of the exchange
+        pl = ops.ep_live_row_plan(host[0].reshape(ep, El), host[1].reshape(ep, El), C, x.device)
+        self.last_ep_plan = pl
+        packed = ops.RowGather.apply(disp, pl.send_idx, pl.send_inv)                         # [Ls, H] live rows only
+        recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, group)          # [Lr, H]
+        recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)                        # slabs [ep*El*C, H]
+        y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rr.contiguous(), *expert_params)
+        y_p = ops.RowGather.apply(y.view(ep * El * C, H), pl.recv_inv, pl.recv_slab)         # live outputs [Lr, H]
+        back_p = ops.AllToAllRows.apply(y_p, pl.out_splits, pl.in_splits, group)             # [Ls, H]
+        back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)                         # [E*C, H], zero on dead slots
+        out = ops.MoECombine.apply(back, w1, w2, st)
         return out, l_aux, counts

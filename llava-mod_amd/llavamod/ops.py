@@ -664,6 +664,70 @@ class AllToAll(torch.autograd.Function):
         return out, None
 
 
+class AllToAllRows(torch.autograd.Function):
+    """Unequal-split all_to_all_single of PACKED live rows [L, H]: rank d receives `in_splits[d]` rows of x and this rank
+    receives `out_splits[s]` rows from rank s (host ints).  Backward is the reverse exchange with the splits swapped.
+    group None: identity (single-GPU test of the decomposed path)."""
+
+    @staticmethod
+    def forward(ctx, x, in_splits, out_splits, group):
+        ctx.group, ctx.in_splits, ctx.out_splits = group, list(in_splits), list(out_splits)
+        if group is None:
+            return x
+        import torch.distributed as dist
+        from .engine import comm_count
+        x = x.contiguous()
+        out = torch.empty((sum(out_splits), x.shape[1]), device=x.device, dtype=x.dtype)
+        comm_count("all_to_all", x)
+        dist.all_to_all_single(out, x, output_split_sizes=ctx.out_splits, input_split_sizes=ctx.in_splits, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.group is None:
+            return g, None, None, None
+        import torch.distributed as dist
+        from .engine import comm_count
+        g = g.contiguous()
+        out = torch.empty((sum(ctx.in_splits), g.shape[1]), device=g.device, dtype=g.dtype)
+        comm_count("all_to_all", g)
+        dist.all_to_all_single(out, g, output_split_sizes=ctx.in_splits, input_split_sizes=ctx.out_splits, group=ctx.group)
+        return out, None, None, None
+
+
+def ep_live_row_plan(used, recv, C, device):
+    """Index maps of the live-row expert-parallel exchange, from HOST counts.
+      used [ep, El]: live slots of MY capacity slabs, by destination rank and its local expert (= st.slots_used)
+      recv [ep, El]: live rows I will receive, by source rank and my local expert (the peers' `used` rows for me)
+    Slab layouts are [ep, El, C] (x H).  Packed order on the wire is (rank, local expert, slot).  Returns int32 device
+    maps: send_idx [Ls] slab position of every live row I send, send_inv [ep*El*C] its packed position or -1; recv_slab
+    [ep*El*C] packed position filling each slab position of the receive buffer or -1, recv_inv [Lr] the inverse; and the
+    split sizes in rows."""
+    import numpy as np
+    used, recv = np.asarray(used, dtype=np.int64), np.asarray(recv, dtype=np.int64)
+    ep, El = used.shape
+
+    def maps(cnt):
+        n = int(cnt.sum())
+        idx = np.empty(n, dtype=np.int32)
+        inv = np.full(ep * El * C, -1, dtype=np.int32)
+        o = 0
+        for r in range(ep):
+            for le in range(El):
+                c = int(cnt[r, le])
+                base = (r * El + le) * C
+                idx[o:o + c] = base + np.arange(c, dtype=np.int32)
+                inv[base:base + c] = o + np.arange(c, dtype=np.int32)
+                o += c
+        return idx, inv
+    send_idx, send_inv = maps(used)
+    recv_inv, recv_slab = maps(recv)
+    t = lambda a: torch.from_numpy(a).to(device)
+    from types import SimpleNamespace
+    return SimpleNamespace(send_idx=t(send_idx), send_inv=t(send_inv), recv_slab=t(recv_slab), recv_inv=t(recv_inv),
+                           in_splits=[int(v) for v in used.sum(1)], out_splits=[int(v) for v in recv.sum(1)])
+
+
 class ExpertFFN(torch.autograd.Function):
     """x: [ep, E_local, C, H] (slabs received from the ep source ranks) -> same shape.  rows: int32
     [ep, E_local] live rows per slab (from the senders' slots_used) or None (compute every row)."""

@@ -153,6 +153,26 @@ class AlignTrainer:
         for k, v in metrics.items():
             self._stored_metrics[train_eval][k].append(v)
 
+    def log(self, logs):
+        """The reference's `log()` (train/align_trainer.py:600-614, dpo_trainer.py same): the stored per-step metrics are
+        AVERAGED into `logs` and the store is DRAINED — without the drain it grows by a few device scalars per step for
+        the whole run.  One host read-back per call (the logging interval), none per step.  Returns `logs`."""
+        train_eval = "train" if "loss" in logs else "eval"
+        for key, metrics in self._stored_metrics[train_eval].items():
+            logs[key] = torch.stack([m.detach().float().reshape(()) for m in metrics]).mean().item()
+        del self._stored_metrics[train_eval]
+        return logs
+
+    def _save_checkpoint(self, model, output_dir, trial=None, metrics=None):
+        """train/align_trainer.py:616-636: with `tune_mm_mlp_adapter` only the adapter is saved (config + `mm_projector.bin`
+        holding the `mm_projector` parameters under their full names); otherwise the full HF-layout checkpoint."""
+        if getattr(self.args, "tune_mm_mlp_adapter", False):
+            keys = ["mm_projector", "vision_resampler"]
+            if getattr(self.args, "use_im_start_end", False):
+                keys.extend(["embed_tokens", "embed_in"])
+            return model.save_mm_adapter(output_dir, keys_to_match=tuple(keys))
+        return model.save_pretrained(output_dir)
+
     # ---- materialising API of the reference (slow path, kept for drop-in parity) ------------------
     def get_p(self, model, inputs):
         """Teacher probabilities softmax(logits[:, :, :151936], fp32) — materialised like the reference."""

@@ -148,3 +148,13 @@ class DPOTrainer:
     def store_metrics(self, metrics, train_eval="train"):
         for k, v in metrics.items():
             self._stored_metrics[train_eval][k].append(v)
+
+    def log(self, logs):
+        """The reference's `log()` (train/align_trainer.py:600-614, dpo_trainer.py same): the stored per-step metrics are
+        AVERAGED into `logs` and the store is DRAINED — without the drain it grows by a few device scalars per step for
+        the whole run.  One host read-back per call (the logging interval), none per step.  Returns `logs`."""
+        train_eval = "train" if "loss" in logs else "eval"
+        for key, metrics in self._stored_metrics[train_eval].items():
+            logs[key] = torch.stack([m.detach().float().reshape(()) for m in metrics]).mean().item()
+        del self._stored_metrics[train_eval]
+        return logs

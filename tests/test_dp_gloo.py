@@ -84,6 +84,50 @@ def _worker(rank, world, port, q):
     (recv * (rank + 1)).sum().backward()                       # grad chunk d returns from rank d scaled by (d+1)
     for dst in range(world):
         assert torch.all(send.grad[dst] == dst + 1)
+    # live-row exchange: only the live rows of each capacity slab travel, through an unequal-split
+    # all_to_all_single sized by the exchanged `slots_used`; it must deliver exactly what the full-slab exchange delivers
+    # on every live row, forward and backward (gather kernel replaced by its torch meaning on CPU)
+    import llavamod.kernels as K
+
+    def gather_rows(src_a, src_b, idx, Hh):
+        out = torch.zeros((idx.numel(), Hh), dtype=src_a.dtype)
+        m = idx >= 0
+        out[m] = src_a[idx[m].long()]
+        return out
+    K.gather_rows = gather_rows
+    El, C, H = 2, 5, 4
+    g = torch.Generator().manual_seed(100 + rank)
+    used = torch.randint(0, C + 1, (world, El), generator=g, dtype=torch.int32)      # my live slots per (dest rank, expert)
+    used[rank, 0] = 0                                                                # an empty slab
+    slab = torch.randn(world * El * C, H, generator=g)
+    for r in range(world):
+        for le in range(El):
+            base = (r * El + le) * C
+            slab[base + int(used[r, le]):base + C] = 0                               # empty slots are zero rows
+    rr = torch.empty_like(used)
+    dist.all_to_all_single(rr, used.contiguous(), group=grp)
+    full_in = slab.clone().requires_grad_(True)
+    full = ops.AllToAll.apply(full_in.view(world, El * C, H), grp).reshape(world * El * C, H)
+    pl = ops.ep_live_row_plan(used.numpy(), rr.numpy(), C, "cpu")
+    assert pl.in_splits == used.sum(1).tolist() and pl.out_splits == rr.sum(1).tolist()
+    live_in = slab.clone().requires_grad_(True)
+    packed = ops.RowGather.apply(live_in, pl.send_idx, pl.send_inv)
+    assert packed.shape[0] == int(used.sum())
+    recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, grp)
+    recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)
+    assert torch.equal(recv.detach(), full.detach())                                 # dead slots: zero rows in both
+    wgt = torch.randn(world * El * C, H, generator=torch.Generator().manual_seed(7 + rank))
+    (full * wgt).sum().backward()
+    (recv * wgt).sum().backward()
+    livemask = (pl.send_inv >= 0)
+    assert torch.equal(live_in.grad[livemask], full_in.grad[livemask]) and float(live_in.grad[~livemask].abs().max()) == 0.0
+    # and the way back: expert outputs of the live rows return to their slots
+    y = recv.detach() * 2.0 + 1.0
+    y_p = ops.RowGather.apply(y, pl.recv_inv, pl.recv_slab)
+    back_p = ops.AllToAllRows.apply(y_p, pl.out_splits, pl.in_splits, grp)
+    back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)
+    back_full = ops.AllToAll.apply(y.view(world, El * C, H), grp).reshape(world * El * C, H)
+    assert torch.equal(back[livemask], back_full[livemask]) and torch.equal(back[livemask], slab[livemask] * 2.0 + 1.0)
     # rank-distinct synthetic shards (bench.py seeds batches with the rank)
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
@@ -218,12 +262,59 @@ def _zero2_worker(rank, world, port, q):
     qkv.note_use(); qkv.grad_done()
     dp.finish()
     assert torch.equal(gb.flat, before) and not dp._handles
+    # an optimizer built BEFORE dp.attach(gb) would keep full-span state and update it from reduce-scattered
+    # gradients — it must refuse
+    layer = build()
+    gb = GradBuffer(layer)
+    dp_late = DataParallel(zero2=True, min_shard_numel=1)
+    try:
+        HipAdamW(gb, dp=dp_late)
+        raise AssertionError("HipAdamW accepted a DataParallel that was not attached to its GradBuffer")
+    except RuntimeError:
+        pass
+    # exact resume of the SHARDED optimizer: per-rank state files, weights from the (replicated) bf16 buffer
+    import tempfile
+    from llavamod.checkpoint import load_optimizer, save_optimizer
+    tmp = os.environ["LMOD_TEST_TMP"]
+    a_layer, a_gb, a_opt, _ = run(True)
+    weights = {n: p.detach().clone() for n, p in a_layer.named_parameters()}
+    path = save_optimizer(a_opt, tmp)
+    assert path.endswith(f"optimizer_rank{rank}_of{world}.pt")
+    a_layer.mlp._calls = 5                                       # pretend the gate drew noise 5 times, then save again
+    save_optimizer(a_opt, tmp)
+    a_gb.zero(); fake_grads(a_gb, 2)
+    a_opt.dp.finish(); a_opt.step(grad_scale=1.0 / world, clear_grads=True)
+    b_layer = build()
+    with torch.no_grad():
+        for n, p in b_layer.named_parameters():
+            p.copy_(weights[n])
+    b_gb = GradBuffer(b_layer)
+    b_dp = DataParallel(bucket_bytes=4096, zero2=True, min_shard_numel=1).attach(b_gb)
+    b_opt = HipAdamW(b_gb, lr=1e-2, weight_decay=0.01, dp=b_dp, max_grad_norm=1.0)
+    load_optimizer(b_opt, tmp)
+    assert b_opt.step_count == 2 and b_layer.mlp._calls == 5
+    b_gb.zero(); fake_grads(b_gb, 2)
+    b_dp.finish(); b_opt.step(grad_scale=1.0 / world, clear_grads=True)
+    for (n, pa), (_, pb) in zip(a_layer.named_parameters(), b_layer.named_parameters()):
+        assert torch.equal(pa, pb), n
+    assert torch.equal(a_opt.m, b_opt.m) and torch.equal(a_opt.v, b_opt.v) and torch.equal(a_opt.master, b_opt.master)
+    # a different shard layout cannot be resumed exactly: refuse instead of mis-assigning moments
+    c_layer = build()
+    c_gb = GradBuffer(c_layer)
+    c_opt = HipAdamW(c_gb, dp=DataParallel(zero2=False).attach(c_gb))
+    try:
+        c_opt.load_state_dict(torch.load(path, weights_only=False))
+        raise AssertionError("optimizer state of another shard layout was accepted")
+    except ValueError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
 
 
 def _spawn(target):
+    import tempfile
+    os.environ["LMOD_TEST_TMP"] = tempfile.mkdtemp(prefix="lmod_gloo_")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

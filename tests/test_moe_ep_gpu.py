@@ -10,8 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("live", [True, False])
 @pytest.mark.parametrize("E,k,T", [(4, 2, 300), (8, 2, 1000), (4, 1, 257)])
-def test_decomposed_equals_fused(E, k, T):
+def test_decomposed_equals_fused(E, k, T, live):
     from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
     from llavamod.model.moe_layer import MoE
     torch.manual_seed(0)
@@ -25,6 +26,7 @@ def test_decomposed_equals_fused(E, k, T):
         a.deepspeed_moe.gate.wg.weight.normal_(0, 0.5)
     b = copy.deepcopy(a)
     b.force_decomposed = True
+    b.ep_live_rows = live              # packed live rows through the unequal-split exchange vs whole [E_local*C, H] slabs
     a.train(); b.train()
     a.deterministic = b.deterministic = True
     x = (torch.randn(T, 256, device="cuda") * 0.5).to(torch.bfloat16)
@@ -38,6 +40,9 @@ def test_decomposed_equals_fused(E, k, T):
         grads = {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None}
         res.append((out.detach(), l_aux.detach(), counts, xi.grad, grads))
     (o1, l1, c1, g1, w1), (o2, l2, c2, g2, w2) = res
+    if live:
+        pl = b.last_ep_plan
+        assert sum(pl.in_splits) == int(b.last_state.slots_used.sum()) <= E * b.last_state.C
     assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(c1, c2)
     assert torch.equal(g1, g2)
     assert set(w1) == set(w2) and len(w1) == 3 * E + 1
