@@ -302,6 +302,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 #ifndef G256_STAGGER
 #define G256_STAGGER 1
 #endif
+// Main-loop experiment knobs (tools/build_gemm_variants.sh builds alt_libs/ with them; tools/gemm_variants_ab.py times the
+// builds in ONE process beside a power / clock trace).  Defaults = the shipped schedule.
+//   G256_STAGE_POS  where a phase issues its 2 LDS-DMA prefetch pieces: 0 before the phase's first barrier (with the
+//                   ds_reads), 1 right after that barrier (head of the MFMA interval), 2 after 8 of the 16 MFMAs,
+//                   3 one piece after 4 and one after 12 MFMAs, 4 one piece with the ds_reads and one after the 16th
+//                   MFMA (the MFMA wave's issue slots are free there; it is about to park at the barrier).  (1-3: one
+//                   stage fewer is outstanding at the counted waits, so they wait vmcnt(2) where 0 waits vmcnt(4); 4
+//                   waits vmcnt(3).)
+//   G256_M32        TIMING ONLY (wrong results): the 16 v_mfma_f32_16x16x32_bf16 of a phase replaced by 8
+//                   v_mfma_f32_32x32x16_bf16 over the SAME fragment registers / LDS reads / staging — what the
+//                   32x32x16 shape does to power, clock and throughput inside this very loop.
+//   G256_ABL        TIMING ONLY ablation bit mask: 1 no LDS-DMA in the loop, 2 no ds_reads in the loop, 4 no counted
+//                   vmcnt waits, 8 no MFMAs, 16 no second barrier of a phase, 32 no first barrier of a phase.
+//   G256_DMA_AUX    cache-policy bits of the LDS-DMA loads (buffer_load ... lds aux): 0 default, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1
+#ifndef G256_DMA_AUX
+#define G256_DMA_AUX 0
+#endif
+//   G256_DEEP       1: deep-prefetch schedule.  Both B half-tile fragment sets stay in registers (+16 VGPRs), so B(nh0) is
+//                   read once per tile and EVERY half-tile slot is free two phases after its tile's P1..P3 read; it is then
+//                   refilled at once with the half-tile of tile t+2 (the two LDS buffers of a kind alternate as before):
+//                       P1: read A(mh0), B(nh0) | prefetch B(nh1) of t+1      P3: read A(mh1) | prefetch A(mh0) of t+2
+//                       P2: read B(nh1)         | prefetch A(mh1) of t+1      P4: no reads    | prefetch B(nh0) of t+2
+//                   Issue order = consumption order (vmcnt retires in order), 4 half-tiles (8 loads per thread) stay in
+//                   flight across the counted waits (vmcnt(8)) instead of 2.
+#ifndef G256_DEEP
+#define G256_DEEP 1
+#endif
+//   G256_EARLYBAR   n in {0, 4, 8}: the phase's SECOND barrier is executed after 16-n of the 16 MFMAs have been issued
+//                   instead of after all of them.  MFMAs touch no LDS, so every hazard the barrier orders is unchanged; the
+//                   other wave of the SIMD (parked at that barrier, operands ready) is released while n MFMAs of this wave
+//                   are still queued, which closes the matrix-pipe bubble at every hand-over (8 per K tile).
+#ifndef G256_EARLYBAR
+#define G256_EARLYBAR 0
+#endif
+//   G256_TRACE      instrumentation build: workgroup G256_TRACE_WG stamps the shader cycle counter (s_getreg SHADER_CYCLES,
+//                   20 bits, no waitcnt) at 7 points of each of the 4 phases of K tile G256_TRACE_T into one VGPR
+//                   (v_writelane) and dumps it; tools/gemm_trace.py prints the per-wave timeline.
+#ifndef G256_TRACE
+#define G256_TRACE 0
+#endif
+#ifndef G256_TRACE_T
+#define G256_TRACE_T 24
+#endif
+#ifndef G256_TRACE_WG
+#define G256_TRACE_WG 1000
+#endif
+#if G256_TRACE
+__device__ uint32_t g256_trace_buf[8 * 64];
+extern "C" int lmod_debug_gemm_trace(uint32_t* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g256_trace_buf), sizeof(uint32_t) * 8 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifndef G256_STAGE_POS
+#define G256_STAGE_POS 0
+#endif
+#ifndef G256_M32
+#define G256_M32 0
+#endif
+#ifndef G256_ABL
+#define G256_ABL 0
+#endif
 
 // MODE 0: plain NT GEMM.  MODE 1 (gemm_swiglu_256): B is the [2N, K] gate-over-up weight; an N tile is 128 output
 // columns fed by 128 gate rows (B half-tile nh0) and the matching 128 up rows (nh1), staged so that every lane
@@ -431,7 +492,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const int nkt = (Kv + 63) >> 6;
 
   // kind: 0 A(mh0), 1 A(mh1), 2 B(nh0), 3 B(nh1); tile index t (may be >= nkt: fully out of bounds)
-  auto stage = [&](int kind, int t) {
+  // pieces jlo..jhi-1 (of 2) of half-tile `kind` of tile t
+  auto stage_j = [&](int kind, int t, int jlo, int jhi) {
     const int k0 = t * 64;
     char* dst = smem + (t & 1) * (4 * G256_SLOT) + kind * G256_SLOT + wave * 2048;
     const bool kmaj = (kind < 2) ? AK : BK;
@@ -442,28 +504,32 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
                                                                     (int)0x80000000u, 0x00020000);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (j < jlo || j >= jhi) continue;
         uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
         if (k0 + wave * 8 + j * 4 + (lane >> 4) >= Kv) v = GEMM_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + j * 1024), 16, v, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + j * 1024), 16, v, 0, 0, G256_DMA_AUX);
       }
     } else {
       const bool dead = (k0 + cchunk * 8 >= Kv);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (j < jlo || j >= jhi) continue;
         uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
         if (dead) v = GEMM_OOB;
-        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, 0);
+        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, G256_DMA_AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, G256_DMA_AUX);
       }
     }
   };
+  auto stage = [&](int kind, int t) { stage_j(kind, t, 0, 2); };
 
   const int li = lane & 15;
   const int rdrow = li * 128;
   const int ph0 = ((lane >> 4) ^ (lane & 7)) * 16;
   const int ph1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
 
-  bf16x8 af[4][2], bfr[2][2];
+  bf16x8 af[4][2], bfr2[2][2][2];      // bfr2[nh]: fragments of B half-tile nh (the classic schedule only uses set 0)
+#define BFR(NH) bfr2[G256_DEEP ? (NH) : 0]
   // MODE 2: per-lane pieces of the transposing read (see the kernel header): k row g*8 + (i>>2) (+4 for the second
   // half of the fragment, +32 per k-step), 8 bytes at (i&3)*8 inside the 32-byte block (m-tile index ^ key)
   const int trk = ((lane >> 4) * 8 + (li >> 2)) * 256 + (li & 3) * 8;
@@ -497,72 +563,221 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       const char* sl = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT;
 #pragma unroll
       for (int nl = 0; nl < 2; ++nl) {
-        bfr[nl][0] = read_tr16(sl, wc * 2 + nl, 0);
-        bfr[nl][1] = read_tr16(sl, wc * 2 + nl, 1);
+        BFR(nh)[nl][0] = read_tr16(sl, wc * 2 + nl, 0);
+        BFR(nh)[nl][1] = read_tr16(sl, wc * 2 + nl, 1);
       }
       return;
     }
     const char* s = smem + (t & 1) * (4 * G256_SLOT) + (2 + nh) * G256_SLOT + wc * 4096 + rdrow;
 #pragma unroll
     for (int nl = 0; nl < 2; ++nl) {
-      bfr[nl][0] = *(const bf16x8*)(s + nl * 2048 + ph0);
-      bfr[nl][1] = *(const bf16x8*)(s + nl * 2048 + ph1);
+      BFR(nh)[nl][0] = *(const bf16x8*)(s + nl * 2048 + ph0);
+      BFR(nh)[nl][1] = *(const bf16x8*)(s + nl * 2048 + ph1);
     }
   };
 #define G256_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define G256_MFMA(MH, NH)                                                                                   \
-  do {                                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (G256_PRIO) __builtin_amdgcn_s_setprio(1);                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-      _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                      \
+#if G256_TRACE
+  uint32_t vtrace = 0;
+#define G256_STAMP(IDX) do { if (t == G256_TRACE_T) { uint32_t c_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_SHADER_CYCLES, 0, 20)" : "=s"(c_) :: "memory"); \
+                                                      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vtrace) : "s"(c_), "n"(IDX)); } } while (0)
+#else
+#define G256_STAMP(IDX) do { } while (0)
+#endif
+#define G256_BARRIER2() do { if (!(G256_ABL & 16)) G256_BARRIER(); } while (0)
+#define G256_BARRIER1() do { if (!(G256_ABL & 32)) G256_BARRIER(); } while (0)
+  // loop-side staging by position (see the knob list above); LOOPSTAGE(pos, ...) issues only if this build stages at `pos`
+#define G256_LOOPSTAGE(POS, KIND, T, JLO, JHI) do { if (G256_STAGE_POS == (POS) && !(G256_ABL & 1)) stage_j(KIND, T, JLO, JHI); } while (0)
+#define G256_VMWAIT() do { if (!(G256_ABL & 4)) { if (G256_STAGE_POS == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  \
+                                                  else if (G256_STAGE_POS == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
+                                                  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } } while (0)
+#if G256_M32
+  typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+  f32x16_t acc32[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc32[i][j][q] = 0.f;
+#define G256_MFMA_BODY(MH, NH, KK, MLLO, MLHI)                                                              \
+      _Pragma("unroll") for (int ml = (MLLO); ml < (MLHI); ++ml)                                            \
+        acc32[(MH) * 2 + (ml & 1)][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                           \
+            BFR(NH)[ml >> 1][KK], af[ml][KK], acc32[(MH) * 2 + (ml & 1)][NH], 0, 0, 0);
+#else
+#define G256_MFMA_BODY(MH, NH, KK, MLLO, MLHI)                                                              \
+      _Pragma("unroll") for (int ml = (MLLO); ml < (MLHI); ++ml)                                            \
         _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                    \
           acc[(MH) * 4 + ml][(NH) * 2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-              bfr[nl][kk], af[ml][kk], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);                         \
+              BFR(NH)[nl][KK], af[ml][KK], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);
+#endif
+#define G256_MFMA(MH, NH, KIND, T)                                                                          \
+  do {                                                                                                      \
+    G256_STAMP(ph_ * 8 + 4);                                                                                \
+    G256_LOOPSTAGE(1, KIND, T, 0, 2);                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    G256_STAMP(ph_ * 8 + 5);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (G256_PRIO) __builtin_amdgcn_s_setprio(1);                                                           \
+    if (!(G256_ABL & 8)) {                                                                                  \
+      G256_MFMA_BODY(MH, NH, 0, 0, 2)                                                                       \
+      if (G256_STAGE_POS == 3) { __builtin_amdgcn_sched_barrier(0); G256_LOOPSTAGE(3, KIND, T, 0, 1); __builtin_amdgcn_sched_barrier(0); } \
+      G256_MFMA_BODY(MH, NH, 0, 2, 4)                                                                       \
+      if (G256_STAGE_POS == 2) { __builtin_amdgcn_sched_barrier(0); G256_LOOPSTAGE(2, KIND, T, 0, 2); __builtin_amdgcn_sched_barrier(0); } \
+      if (G256_EARLYBAR == 8) { __builtin_amdgcn_sched_barrier(0); G256_BARRIER2(); __builtin_amdgcn_sched_barrier(0); } \
+      G256_MFMA_BODY(MH, NH, 1, 0, 2)                                                                       \
+      if (G256_STAGE_POS == 3) { __builtin_amdgcn_sched_barrier(0); G256_LOOPSTAGE(3, KIND, T, 1, 2); __builtin_amdgcn_sched_barrier(0); } \
+      if (G256_EARLYBAR == 4) { __builtin_amdgcn_sched_barrier(0); G256_BARRIER2(); __builtin_amdgcn_sched_barrier(0); } \
+      G256_MFMA_BODY(MH, NH, 1, 2, 4)                                                                       \
+    } else {                                                                                                \
+      G256_LOOPSTAGE(2, KIND, T, 0, 2); G256_LOOPSTAGE(3, KIND, T, 0, 2);                                   \
+    }                                                                                                       \
     if (G256_PRIO) __builtin_amdgcn_s_setprio(0);                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
+    G256_STAMP(ph_ * 8 + 6);                                                                                \
+    G256_LOOPSTAGE(4, KIND, T, 1, 2);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (G256_EARLYBAR == 0 || (G256_ABL & 8)) G256_BARRIER2();                                              \
   } while (0)
+#define G256_RA(T, MH) do { if (!(G256_ABL & 2)) readA(T, MH); } while (0)
+#define G256_RB(T, NH) do { if (!(G256_ABL & 2)) readB(T, NH); } while (0)
 
+#if G256_DEEP
+  // deep-prefetch schedule (see the knob list): prologue = what the steady state would have issued before P1 of tile 0
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // A(mh0)_0, B(nh0)_0 landed
+  G256_BARRIER();
+  if (G256_STAGGER && wr == 1) G256_BARRIER();
+#define G256_DSTAGE(KIND, T) do { if (!(G256_ABL & 1)) stage(KIND, T); } while (0)
+#define G256_DWAIT() do { if (!(G256_ABL & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
+  for (int t = 0; t < nkt; ++t) {
+    // ---- P1: quadrant (mh0, nh0) ----
+    { constexpr int ph_ = 0; G256_STAMP(ph_ * 8 + 0);
+    G256_RA(t, 0); G256_RB(t, 0);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_DSTAGE(3, t + 1);                                // slot last read in P2 of tile t-1
+    G256_STAMP(ph_ * 8 + 2);
+    G256_DWAIT();                                         // retires B(nh1)_t for P2
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(0, 0, 0, 0);
+    G256_STAMP(ph_ * 8 + 7); }
+    // ---- P2: quadrant (mh0, nh1) ----
+    { constexpr int ph_ = 1; G256_STAMP(ph_ * 8 + 0);
+    G256_RB(t, 1);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_DSTAGE(1, t + 1);                                // slot last read in P3 of tile t-1
+    G256_STAMP(ph_ * 8 + 2);
+    G256_DWAIT();                                         // retires A(mh1)_t for P3
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(0, 1, 0, 0);
+    G256_STAMP(ph_ * 8 + 7); }
+    // ---- P3: quadrant (mh1, nh1) ----
+    { constexpr int ph_ = 2; G256_STAMP(ph_ * 8 + 0);
+    G256_RA(t, 1);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_DSTAGE(0, t + 2);                                // slot last read in P1 of this tile
+    G256_STAMP(ph_ * 8 + 2);
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(1, 1, 0, 0);
+    G256_STAMP(ph_ * 8 + 7); }
+    // ---- P4: quadrant (mh1, nh0): B(nh0) fragments are still in registers ----
+    { constexpr int ph_ = 3; G256_STAMP(ph_ * 8 + 0);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_DSTAGE(2, t + 2);                                // slot last read in P1 of this tile
+    G256_STAMP(ph_ * 8 + 2);
+    G256_DWAIT();                                         // retires A(mh0)_{t+1}, B(nh0)_{t+1} for the next P1
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(1, 0, 0, 0);
+    G256_STAMP(ph_ * 8 + 7); }
+  }
+#undef G256_DSTAGE
+#undef G256_DWAIT
+#else
   // prologue: tile 0 in issue order A(mh0), B(nh0), B(nh1), A(mh1); first reads need the first two
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   G256_BARRIER();
+  if (G256_ABL & 2) {                 // ablation: fragments are read once, here (after the whole first tile has landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G256_BARRIER();
+    readA(0, 0); readB(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   if (G256_STAGGER && wr == 1) G256_BARRIER();   // stagger the second wave row by one barrier
 
   for (int t = 0; t < nkt; ++t) {
     // ---- P1: quadrant (mh0, nh0) ----
-    readA(t, 0); readB(t, 0);
-    stage(0, t + 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires B(nh1)_t for P2
-    G256_BARRIER();
-    G256_MFMA(0, 0);
-    G256_BARRIER();
+    { constexpr int ph_ = 0; G256_STAMP(ph_ * 8 + 0);
+    G256_RA(t, 0); G256_RB(t, 0);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_LOOPSTAGE(0, 0, t + 1, 0, 2); G256_LOOPSTAGE(4, 0, t + 1, 0, 1);
+    G256_STAMP(ph_ * 8 + 2);
+    G256_VMWAIT();                                        // retires B(nh1)_t for P2
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(0, 0, 0, t + 1);
+    G256_STAMP(ph_ * 8 + 7); }
     // ---- P2: quadrant (mh0, nh1) ----
-    readB(t, 1);
-    stage(2, t + 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(mh1)_t for P3
-    G256_BARRIER();
-    G256_MFMA(0, 1);
-    G256_BARRIER();
+    { constexpr int ph_ = 1; G256_STAMP(ph_ * 8 + 0);
+    G256_RB(t, 1);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_LOOPSTAGE(0, 2, t + 1, 0, 2); G256_LOOPSTAGE(4, 2, t + 1, 0, 1);
+    G256_STAMP(ph_ * 8 + 2);
+    G256_VMWAIT();                                        // retires A(mh1)_t for P3
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(0, 1, 2, t + 1);
+    G256_STAMP(ph_ * 8 + 7); }
     // ---- P3: quadrant (mh1, nh1) ----
-    readA(t, 1);
-    stage(3, t + 1);
-    G256_BARRIER();
-    G256_MFMA(1, 1);
-    G256_BARRIER();
+    { constexpr int ph_ = 2; G256_STAMP(ph_ * 8 + 0);
+    G256_RA(t, 1);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_LOOPSTAGE(0, 3, t + 1, 0, 2); G256_LOOPSTAGE(4, 3, t + 1, 0, 1);
+    G256_STAMP(ph_ * 8 + 2);
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(1, 1, 3, t + 1);
+    G256_STAMP(ph_ * 8 + 7); }
     // ---- P4: quadrant (mh1, nh0) ----
-    readB(t, 0);
-    stage(1, t + 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(mh0)_{t+1}, B(nh0)_{t+1} for next P1
-    G256_BARRIER();
-    G256_MFMA(1, 0);
-    G256_BARRIER();
+    { constexpr int ph_ = 3; G256_STAMP(ph_ * 8 + 0);
+    G256_RB(t, 0);
+    G256_STAMP(ph_ * 8 + 1);
+    G256_LOOPSTAGE(0, 1, t + 1, 0, 2); G256_LOOPSTAGE(4, 1, t + 1, 0, 1);
+    G256_STAMP(ph_ * 8 + 2);
+    G256_VMWAIT();                                        // retires A(mh0)_{t+1}, B(nh0)_{t+1} for next P1
+    G256_STAMP(ph_ * 8 + 3);
+    G256_BARRIER1();
+    G256_MFMA(1, 0, 1, t + 1);
+    G256_STAMP(ph_ * 8 + 7); }
   }
+#endif
   if (G256_STAGGER && wr == 0) G256_BARRIER();   // re-balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the (out-of-bounds) tail prefetch
+#if G256_TRACE
+  if (blockIdx.x == G256_TRACE_WG) g256_trace_buf[wave * 64 + lane] = vtrace;
+#endif
+#if G256_M32
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][j][q] = acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + q];
+#endif
+#undef G256_MFMA_BODY
+#undef G256_LOOPSTAGE
+#undef G256_VMWAIT
+#undef G256_BARRIER2
+#undef G256_BARRIER1
+#undef G256_RA
+#undef G256_RB
 #undef G256_MFMA
 #undef G256_BARRIER
+#undef BFR
+#undef G256_STAMP
 
   // ---- epilogue: lane holds, for each mt, row (lane&15) and 16 contiguous columns ----
   const int g = lane >> 4;
