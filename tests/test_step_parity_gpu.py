@@ -222,45 +222,38 @@ def _routing_report(student, o_student):
     return agree / max(1, total), worst_margin
 
 
-@pytest.mark.parametrize("ragged,noise", [(False, True), (True, False)])
-def test_seeded_mid_mimic_step_vs_oracle(ragged, noise):
-    """Mid-size mimic step vs the oracle on the same seeded inputs.  The router argmax is discontinuous:
-    bf16 activations can break a near-tie differently from the fp32 oracle for a few tokens.  So the
-    test (1) requires >= 97% of routing decisions to agree and every disagreement to be a near-tie,
-    then (2) re-runs the oracle with the GPU path's expert picks forced and requires tight agreement
-    of the losses and of every trainable tensor's gradient."""
+def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97):
+    """One mimic step vs the oracle on the same seeded inputs.  The router argmax is discontinuous: bf16 activations can
+    break a near-tie differently from the fp32 oracle for a few tokens.  So the case (1) requires >= `min_agree` of the routing
+    decisions to agree and every disagreement to be a near-tie, then (2) re-runs the oracle with the GPU path's expert picks
+    forced and requires tight agreement of the losses (1e-3) and of every trainable tensor's gradient (2x its bf16 floor)."""
     from llavamod.engine import GradBuffer
     from llavamod.train.align_trainer import AlignTrainer
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    vc, sc, tc = _mid_cfgs()
-    o_student, o_teacher = _seeded_pair(3, sc, tc, vc)
-    batch = _mid_batch(11, 3, 48, sc.vocab_size, vc.image_size, ragged)
-    Sp = batch["input_ids"].shape[1] - 1 + vc.num_patches
-    noises = [omoe.gumbel_noise((3 * Sp, sc.num_experts), torch.Generator().manual_seed(20 + i)) if noise else None
-              for i in range(len(sc.moe_layers_idx))]
+    o_student, o_teacher = _seeded_pair(seed, sc, tc, vc)
     student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
     for m, nz in zip(student.moe_layers(), noises):
         m.deterministic = nz is None
         m.gate_noise = nz
     GradBuffer(student)
     hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    Va = min(olosses.ALIGN_VOCAB, sc.vocab_size, tc.vocab_size)
     tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
-                                                               loss_type="kd_lm", moe_loss_enable=True))(),
-                      align_vocab=sc.vocab_size)
+                                                               loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=Va)
     student.train()
     loss, outs = tr.compute_loss(student, hb, return_outputs=True)
     loss.backward()
     # (1) free-running oracle: routing agreement
     o_student.train(); o_teacher.eval(); o_student.set_gate_noise(noises)
-    mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va)
     frac, margin = _routing_report(student, o_student)
-    assert frac >= 0.97, frac
+    assert frac >= min_agree, frac
     assert margin <= 2e-2, margin
     # (2) oracle with the GPU picks forced: tight parity
     o_student.zero_grad()
     for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
         om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
-    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va)
     for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
         got, exp = float(outs[k]), float(logs_o[k])
         assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
@@ -272,15 +265,41 @@ def test_seeded_mid_mimic_step_vs_oracle(ragged, noise):
     tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(noises)
     for hm, om in zip(student.moe_layers(), _oracle_moes(tw_s)):
         om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
-    _, logs_f, _, _ = mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=sc.vocab_size)
+    _, logs_f, _, _ = mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=Va)
     fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
-    worst = (0.0, None, 0.0)
-    for n, ref in ograds.items():
-        e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
-        assert e <= max(2.0 * floor, 5e-3), (n, e, floor)
-        worst = max(worst, (e, n, floor))
-    print(f"mid mimic (ragged={ragged}, noise={noise}): worst gradient error {worst[0]:.4f} ({worst[1]}), its bf16 floor "
-          f"{worst[2]:.4f}; loss floor {abs(float(logs_f['loss']) - float(logs_o['loss'])) / abs(float(logs_o['loss'])):.2e}")
+    worst = _check_grads_floor(hgrads, ograds, fgrads, tag)
+    print(f"{tag}: routing agreement {frac * 100:.1f} %; loss floor "
+          f"{abs(float(logs_f['loss']) - float(logs_o['loss'])) / abs(float(logs_o['loss'])):.2e}")
+    return worst
+
+
+@pytest.mark.parametrize("ragged,noise", [(False, True), (True, False)])
+def test_seeded_mid_mimic_step_vs_oracle(ragged, noise):
+    """Mid-size mimic step (hd 128 decoder, hd 64 ViT, multi-span labels; ragged / Gumbel-noise variants) vs the oracle."""
+    vc, sc, tc = _mid_cfgs()
+    batch = _mid_batch(11, 3, 48, sc.vocab_size, vc.image_size, ragged)
+    Sp = batch["input_ids"].shape[1] - 1 + vc.num_patches
+    noises = [omoe.gumbel_noise((3 * Sp, sc.num_experts), torch.Generator().manual_seed(20 + i)) if noise else None
+              for i in range(len(sc.moe_layers_idx))]
+    _mimic_parity_case(vc, sc, tc, 3, batch, noises, f"mid mimic (ragged={ragged}, noise={noise})")
+
+
+def test_qwen2_geometry_mimic_step_vs_oracle():
+    """The Qwen2 shells' geometry (VERDICT r02 missing #4 / next #6b; dense2sparse_distillation.sh:20 trains
+    `llavaqwen-2-0.5b`): student = Qwen2-0.5B attention shape — H 896, 14 heads of 64, 2 KV heads (GQA group 7), rope theta
+    1e6, QKV bias — with V 151936; teacher = Qwen2-7B attention shape — H 3584, 28 heads of 128, 4 KV heads (group 7) — with
+    V 152064 > 151936, so `get_p` / `get_logp`'s `[:, :, :151936]` slice (align_trainer.py:473,497) is live.  Two layers each
+    (MoE on the student's layer 0), FFN widths cut 4x (1216 / 4736) to keep the CPU oracle in seconds; ragged batch."""
+    vc = VisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                      image_size=56, patch_size=14, select_layer=-2)
+    sc = DecoderConfig(vocab_size=151936, hidden_size=896, intermediate_size=1216, num_hidden_layers=2,
+                       num_attention_heads=14, num_key_value_heads=2, moe_layers_idx=[0], num_experts=4,
+                       top_k_experts=2, capacity_factor=1.5, min_capacity=0, rope_theta=1000000.0)
+    tc = DecoderConfig(vocab_size=152064, hidden_size=3584, intermediate_size=4736, num_hidden_layers=2,
+                       num_attention_heads=28, num_key_value_heads=4, rope_theta=1000000.0)
+    assert sc.hidden_size // sc.num_attention_heads == 64 and tc.hidden_size // tc.num_attention_heads == 128
+    batch = _mid_batch(31, 2, 44, 151000, vc.image_size, True)
+    _mimic_parity_case(vc, sc, tc, 9, batch, [None], "Qwen2 geometry (hd 64 GQA-7 student, V 152064 teacher)")
 
 
 def test_mid_mimic_step_free_running_routing():
@@ -331,6 +350,76 @@ def test_mid_mimic_step_free_running_routing():
     for n, ref in ograds.items():
         e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
         assert e <= max(2.0 * floor, 5e-3), (n, e, floor)
+
+
+def test_mid_mimic_step_free_running_270_tokens():
+    """Free-running at 270 tokens with the PLAIN router init (no scaling of `wg`, no seed search, no forced picks anywhere;
+    VERDICT r02 next #6d).  With N(0, 0.02) routers the median decision margin is ~0.1 and the bf16 noise of a router logit is
+    ~0.003-0.01 (the oracle's own bf16 twin flips 2-4 of the 270 x 2 decisions per layer), so identical picks cannot be demanded
+    at this size — a seed for which all ~1080 decisions clear the noise does not exist in practice (P ~ 0.9^1080).  What is
+    demanded instead, of two runs that each route on their own:
+      * >= 98 % of the decisions agree and every disagreement is a near-tie (margin <= 2e-2 of the token's largest logit);
+      * the four logged loss scalars agree to north_star's 1e-3 relative — flips move single tokens between near-equal experts,
+        the losses are averages over hundreds of tokens;
+      * gradients of everything that is not an expert / router tensor (projector, dense FFNs) are within 2x their bf16 floor
+        (the twin's floor is taken free-running as well, so it contains the twin's own flips);
+      * expert and router gradients: relative Frobenius error within 2x the twin's own free-running Frobenius error + the mass
+        the flipped tokens can move, 2 * sqrt(flips / routed tokens)."""
+    from llavamod.engine import GradBuffer
+    from llavamod.train.align_trainer import AlignTrainer
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    vc, sc, tc = _mid_cfgs()
+    o_student, o_teacher = _seeded_pair(1001, sc, tc, vc)
+    batch = _mid_batch(1008, 2, 120, sc.vocab_size, vc.image_size, False)
+    T = 2 * (120 - 1 + vc.num_patches)
+    assert T >= 256
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=sc.vocab_size)
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    for m in student.moe_layers():
+        m.deterministic = True
+    GradBuffer(student)
+    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                               loss_type="kd_lm", moe_loss_enable=True))(),
+                      align_vocab=sc.vocab_size)
+    student.train()
+    loss, outs = tr.compute_loss(student, hb, return_outputs=True)
+    loss.backward()
+    frac, margin = _routing_report(student, o_student)
+    flips = []
+    for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
+        i1, i2, _, _ = om.last_picks
+        flips.append(int(((hm.last_state.idx1.cpu().long() != i1) | (hm.last_state.idx2.cpu().long() != i2)).sum()))
+    assert frac >= 0.98 and margin <= 2e-2, (frac, margin, flips)
+    for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
+        got, exp = float(outs[k].detach()), float(logs_o[k].detach())
+        assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp, flips)
+    # the bf16 twin, free-running too
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise([None, None])
+    mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=sc.vocab_size)
+    ograds = {U.oracle_to_hip_key(n): p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+    fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
+    hgrads = _grads_of(student)
+    assert set(ograds) == set(hgrads)
+    routed = 2 * T
+    allow = 2.0 * (max(flips) / routed) ** 0.5
+    worst_dense, worst_moe = (0.0, None, 0.0), (0.0, None, 0.0)
+    for n, ref in ograds.items():
+        if ref.abs().max() == 0:
+            continue
+        if "deepspeed_moe" in n:
+            e, floor = _froerr(hgrads[n], ref), _froerr(fgrads[n].float(), ref)
+            assert e <= 2.0 * floor + allow + 5e-3, (n, e, floor, allow)
+            worst_moe = max(worst_moe, (e, n, floor))
+        else:
+            e, floor = U.relerr(hgrads[n], ref), U.relerr(fgrads[n].float(), ref)
+            assert e <= max(2.0 * floor, 5e-3), (n, e, floor)
+            worst_dense = max(worst_dense, (e, n, floor))
+    print(f"free-running 270 tokens: {frac * 100:.2f} % of picks agree (flips per layer {flips}, worst margin {margin:.2e}); "
+          f"loss {float(loss):.5f} vs {float(loss_o):.5f}; worst dense grad err {worst_dense[0]:.4f} (floor {worst_dense[2]:.4f}), "
+          f"worst expert/router grad Frobenius err {worst_moe[0]:.4f} (twin {worst_moe[2]:.4f}, flip allowance {allow:.4f})")
 
 
 def test_finetune_student_and_top1_step():
