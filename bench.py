@@ -132,7 +132,7 @@ def _mem_total_gb():
     return 0.0
 
 
-def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto"):
+def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None):
     """The oracle (fp32 PyTorch restatement of the reference, oracle/) timed on this box's host cores on ONE sample of the
     same workload (config 2, B=1, S=2048): teacher forward + student forward/backward + losses (no optimizer step).
 
@@ -182,14 +182,42 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto"):
         old = [(m.deterministic, m.gate_noise) for m in moes]
         for m in moes:
             m.deterministic, m.gate_noise = True, None
-        with torch.no_grad():
-            _, outs = trainer.compute_loss(student, b, return_outputs=True)
+        grad_cmp = None
+        if gb is not None:
+            # FREE-RUNNING full-depth gradients too: the GPU step's backward (both sides route on their own, no forced picks)
+            # against the oracle's, relative Frobenius error of a sample of trainable tensors
+            from oracle.llava import hip_to_oracle_key
+            gb.flat.zero_()
+            loss_g, outs = trainer.compute_loss(student, b, return_outputs=True)
+            loss_g.backward()
+            torch.cuda.synchronize()
+            ograd = {n: p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+            want = ("model.mm_projector.image_spatial_proj.0.weight", "model.mm_projector.image_spatial_proj.2.weight",
+                    "model.layers.23.mlp.down_proj.weight", "model.layers.1.mlp.gate_proj.weight",
+                    "model.layers.0.mlp.deepspeed_moe.gate.wg.weight", "model.layers.22.mlp.deepspeed_moe.gate.wg.weight",
+                    "model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.0.up_proj.weight",
+                    "model.layers.12.mlp.deepspeed_moe.experts.deepspeed_experts.3.down_proj.weight")
+            named = dict(student.named_parameters())
+            grad_cmp = {}
+            for n in want:
+                og = ograd.get(hip_to_oracle_key(n))
+                hg = getattr(named.get(n), "main_grad", None)
+                if og is None or hg is None:
+                    continue
+                hg = hg.detach().float().cpu()
+                grad_cmp[n] = round(float((hg - og).norm() / og.norm().clamp_min(1e-30)), 5)
+            gb.flat.zero_()
+        else:
+            with torch.no_grad():
+                _, outs = trainer.compute_loss(student, b, return_outputs=True)
         for m, (d, n) in zip(moes, old):
             m.deterministic, m.gate_noise = d, n
         loss_delta = {}
         for k in ("loss", "loss/align", "loss/lm", "loss/moe_balance"):
             g, c = float(outs[k].detach()), float(logs[k].detach())
             loss_delta[k] = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "rel": round(abs(g - c) / max(abs(c), 1e-30), 6)}
+        if grad_cmp:
+            loss_delta["grad_rel_frobenius_free_running"] = grad_cmp
         sample = (f"oracle fp32 torch-CPU mimic step at FULL depth (32-layer teacher fwd + 24-layer MoE student fwd/bwd + "
                   f"23-layer ViT x2 + losses; no optimizer), B=1 S=2048, same weights and batch as the GPU models "
                   f"(host RAM {mem:.0f} GB): {tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s")
@@ -491,7 +519,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:
                 out["cpu_baseline"] = cpu_baseline(student, teacher, trainer if args.stage == "mimic" else None,
-                                                   args.cpu_baseline if args.stage == "mimic" else "sample")
+                                                   args.cpu_baseline if args.stage == "mimic" else "sample", gb=gb)
             except Exception as e:                              # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(out), flush=True)

@@ -35,6 +35,15 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, i
                       int ldc, int batch, long long strideA, long long strideB, long long strideC, const int* m_valid,
                       const int* k_valid, int act, int out_f32, int accumulate, hipStream_t stream);
 
+/* Fused q/k/v projection + rotary embedding: C[M x N] = rope(A W^T + bias), W = [Wq; Wk; Wv] stored as ONE [N x K] matrix.
+ * Replaces `self.q_proj / k_proj / v_proj` followed by `apply_rotary_pos_emb` (qwen2/modeling_qwen2.py:262-264, :146-171;
+ * tables :119-134) in ONE launch: heads are 128 wide, columns [0, rope_cols) hold the q and k heads and are rotated in the GEMM
+ * epilogue with the bf16 cos/sin rows [max_pos x 128] of position pos[row] (int32 [M]); columns >= rope_cols (v) are stored
+ * as computed.  Results are bit-identical to lmod_gemm_bf16_nt + lmod_rope.
+ * Requires K % 8 == 0, N % 16 == 0, rope_cols % 256 == 0, lda/ldw/ldc % 8 == 0, A/W/C 16-byte aligned. */
+int lmod_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, const void* bias, int M, int N, int K, int lda, int ldw,
+                            int ldc, const void* cos_t, const void* sin_t, const int* pos, int rope_cols, hipStream_t stream);
+
 /* Fused SwiGLU MLP input half: act_out[b] (M x N) = silu(A Wg^T) * (A Wu^T), W = [Wg; Wu] stored as ONE [2N x K]
  * matrix (gate rows first — the fused gate_proj/up_proj weight; qwen2/modeling_qwen2.py:175-187, MoE experts
  * llava_qwen2_moe.py:536-546).  gu_out (may be NULL): [M x 2N] bf16 pre-activations [gate | up] kept for backward.

@@ -39,6 +39,12 @@ __device__ __forceinline__ float bfround(float f) { return __uint_as_float(pack2
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// sigmoid / SiLU with ONE v_rcp_f32 (<= 1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp, 3 fma, v_div_fmas,
+// v_div_fixup = 10 VALU per element): the SwiGLU GEMM epilogues hold 64-128 elements per lane and were VALU-bound on it.  The
+// standalone row kernels use the same helpers, so fused and unfused paths stay bit-identical to each other.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -34,6 +34,8 @@ struct GemmP {
   void* C2; int ldc2; long long sC2;   // gemm_swiglu_256 only: optional [M, 2N] gate|up pre-activations
   int splitk, kchunk;                  // MODE 0, batch 1, fp32 accumulate: deterministic split-K (lmod_gemm_wgrad_bf16_nt)
   float* ws; int* counters;            //   ws [splitk, M, N] partial tiles, counters [tiles] arrival semaphores (self-resetting)
+  // MODE 5 (lmod_gemm_qkv_rope_bf16): rotary embedding of head-dim-128 heads in the epilogue
+  const bf16_t* rope_cos; const bf16_t* rope_sin; const int* rope_pos; int rope_cols;
 };
 
 #define GEMM_OOB 0x80000000u
@@ -45,7 +47,7 @@ __device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float g0 = bfround(v[2 * k]), g1 = bfround(v[2 * k + 1]);
-    const float s0 = bfround(g0 / (1.f + __expf(-g0))), s1 = bfround(g1 / (1.f + __expf(-g1)));
+    const float s0 = bfround(fast_silu(g0)), s1 = bfround(fast_silu(g1));
     o[k] = pack2bf(s0 * bfround(v[8 + 2 * k]), s1 * bfround(v[8 + 2 * k + 1]));
   }
   return o;
@@ -60,7 +62,7 @@ __device__ __forceinline__ void swiglu_bwd8(const float (&d)[8], const u32x4 g, 
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float dd = bfround(d[2 * k + e]);                 // the standalone path rounds dact to bf16 in HBM
-      const float sg = 1.f / (1.f + __expf(-gg[e]));
+      const float sg = fast_sigmoid(gg[e]);
       rg[e] = dd * uu[e] * (sg * (1.f + gg[e] * (1.f - sg)));
       ru[e] = dd * (gg[e] * sg);
     }
@@ -71,7 +73,7 @@ __device__ __forceinline__ void swiglu_bwd8(const float (&d)[8], const u32x4 g, 
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-  if (act == 2) return v / (1.f + __expf(-1.702f * v));
+  if (act == 2) return v * fast_sigmoid(1.702f * v);
   return v;
 }
 
@@ -375,6 +377,12 @@ extern "C" int lmod_debug_gemm_trace(uint32_t* host_out) {
 // conflict-free.  Columns are in natural order, so a lane owns 4 groups of 4 contiguous output columns.
 // MODE 3 (the step's wgrad): A = dY^T K-contiguous as in MODE 0, B = X reduction-major as in MODE 2 — only dY needs
 // a transposed copy, and two thirds of the operand fragments keep the full-rate ds_read_b128 path.
+// MODE 5 (fused QKV projection + RoPE, lmod_gemm_qkv_rope_bf16): MODE 0's loop; a 256-column tile is two whole heads of
+// 128 and a wave column owns 64 of them, so the rotate_half partner (feature f +- 64) of every value sits in the NEIGHBOURING
+// wave column at the same lane / register position.  The epilogue rounds acc + bias to bf16 (what the unfused path stores),
+// swaps those images between wave columns 2c <-> 2c+1 through the (now idle) 128 KiB of LDS, and applies
+// q*cos + rotate_half(q)*sin with the roundings of rope_kernel (rowops.hip) — bit-identical to GEMM + lmod_rope, one pass
+// over the QKV buffer less.  Tiles at or past rope_cols (the V heads) are stored as they are.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       if constexpr (BK) {
         const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
         voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
-      } else if (MODE == 0 || MODE == 4) {
+      } else if (MODE == 0 || MODE == 4 || MODE == 5) {
         const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       } else {       // half h = gate (0) / up (1) rows of the same 128 output columns
@@ -840,6 +848,69 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       }
     }
     if (!(SPLIT_OK && p.splitk > 1)) return;
+  }
+  if constexpr (MODE == 5) {
+    const int cb = col0 + wc * 64 + g * 16;
+    float bia[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) bia[x] = (p.bias && cb + x < p.N) ? bf2f(p.bias[min(cb + x, p.N - 1)]) : 0.f;
+    u32x4 own[8][2];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q] + bia[nt * 4 + q];
+      own[mt][0] = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      own[mt][1] = (u32x4){pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+    }
+    const bool rot = col0 < p.rope_cols;            // workgroup-uniform: rope_cols is a multiple of 256 (host-checked)
+    bf16_t* Cb5 = (bf16_t*)p.C + (long long)bz * p.sC;
+    if (rot) {
+      __syncthreads();                              // every wave is done with the operand tiles in LDS
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) *(u32x4*)(smem + ((wave * 8 + mt) * 2 + hx) * 1024 + lane * 16) = own[mt][hx];
+      __syncthreads();
+      const int fh = (wc & 1) * 64 + g * 16;         // feature of v[0] inside its head
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = row0 + wr * 128 + mt * 16 + li;
+        if (row >= Mv || cb >= p.N) continue;
+        const int ps = p.rope_pos[(long long)bz * p.M + row];
+        const bf16_t* cp = p.rope_cos + (long long)ps * 128 + fh;
+        const bf16_t* sp = p.rope_sin + (long long)ps * 128 + fh;
+        u32x4 o[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          const u32x4 pr = *(const u32x4*)(smem + (((wave ^ 1) * 8 + mt) * 2 + hx) * 1024 + lane * 16);
+          const u32x4 cc = *(const u32x4*)(cp + hx * 8), ss = *(const u32x4*)(sp + hx * 8);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float x0 = bflo(own[mt][hx][k]), x1 = bfhi(own[mt][hx][k]);
+            float y0 = bflo(pr[k]), y1 = bfhi(pr[k]);
+            if (!(wc & 1)) { y0 = -y0; y1 = -y1; }    // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin
+            o[hx][k] = pack2bf(bfround(x0 * bflo(cc[k])) + bfround(y0 * bflo(ss[k])),
+                               bfround(x1 * bfhi(cc[k])) + bfround(y1 * bfhi(ss[k])));
+          }
+        }
+        bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
+        *(u32x4*)op = o[0];
+        *(u32x4*)(op + 8) = o[1];
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = row0 + wr * 128 + mt * 16 + li;
+        if (row >= Mv || cb >= p.N) continue;
+        bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
+        *(u32x4*)op = own[mt][0];
+        *(u32x4*)(op + 8) = own[mt][1];
+      }
+    }
+    return;
   }
   if constexpr (MODE == 4) {
     // fused SwiGLU backward (lmod_gemm_swiglu_bwd_bf16) as its OWN instantiation: the accumulators are d(act); with the
@@ -1467,6 +1538,36 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   if (big) launch_256<0>(p, nwg, stream);
   else hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  return lmod_launch_status();
+}
+
+// C[M, N] = rope(A W^T + bias): the decoder's fused q/k/v projection with the rotary embedding applied in the GEMM epilogue
+// (qwen2/modeling_qwen2.py:262-264 + apply_rotary_pos_emb :146-171).  Heads are 128 wide; columns [0, rope_cols) are the q and
+// k heads (rotated with cos/sin [max_pos, 128] bf16 rows pos[row]), the rest (v) is stored as computed.  Bit-identical to
+// lmod_gemm_bf16_nt followed by lmod_rope.  rope_cols % 256 == 0, N % 16 == 0, C 16-byte aligned with ldc % 8 == 0.
+int lmod_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, const void* bias, int M, int N, int K, int lda, int ldw,
+                            int ldc, const void* cos_t, const void* sin_t, const int* pos, int rope_cols, hipStream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0) return LMOD_OK;
+  if (!A || !W || !C || !cos_t || !sin_t || !pos) return LMOD_EINVAL;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || lda < K || ldw < K || ldc < N || (ldc & 7) || (N & 15)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15)) return LMOD_EINVAL;
+  if (rope_cols < 0 || rope_cols > N || (rope_cols & 255)) return LMOD_EINVAL;
+  if ((long long)255 * lda * 2 + (long long)K * 2 >= 0x7fffffffLL || (long long)255 * ldw * 2 + (long long)K * 2 >= 0x7fffffffLL)
+    return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = C; p.bias = (const bf16_t*)bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc;
+  p.batch = 1; p.sA = 0; p.sB = 0; p.sC = 0; p.m_valid = nullptr; p.k_valid = nullptr;
+  p.act = 0; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
+  p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
+  p.rope_cos = (const bf16_t*)cos_t; p.rope_sin = (const bf16_t*)sin_t; p.rope_pos = pos; p.rope_cols = rope_cols;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  const long long nwg = (long long)p.tiles_m * p.tiles_n;
+  if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  static bool a5 = false;
+  allow_lds(gemm_256_kernel<5>, 8 * G256_SLOT, a5);
+  hipLaunchKernelGGL(gemm_256_kernel<5>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   return lmod_launch_status();
 }
 

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, con
 }
 
 // ------------------------------------------------------------------ SwiGLU
-__device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
+__device__ __forceinline__ float silu_f(float g) { return fast_silu(g); }
 
 // seg_valid != NULL: rows are grouped in segments of seg_rows (MoE capacity slabs); rows at or past
 // seg_valid[segment] are NOT read and are written as zeros (keeps dead capacity slots finite).
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
       float rg[2], ru[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float sg = 1.f / (1.f + __expf(-gg[e]));
+        const float sg = fast_sigmoid(gg[e]);
         const float si = gg[e] * sg;
         rg[e] = dd[e] * uu[e] * (sg * (1.f + gg[e] * (1.f - sg)));
         ru[e] = dd[e] * si;

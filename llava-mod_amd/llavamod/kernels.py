@@ -43,6 +43,24 @@ def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False
     return out
 
 
+def qkv_rope_fusable(x, w, nrot_heads, hd, out=None):
+    """Can `gemm_qkv_rope` take this projection?  (head dim 128; an even number of rotated heads so that the q|k block ends on
+    a 256-column tile boundary; enough rows for the 256-tile kernel to be the right choice.)"""
+    return hd == 128 and nrot_heads % 2 == 0 and w.shape[0] % 16 == 0 and x.shape[0] >= 512
+
+
+def gemm_qkv_rope(x, w, bias, cos_t, sin_t, pos, nrot_heads, out=None):
+    """out[T, N] = rope(x @ w^T + bias) on the first nrot_heads heads of 128 (q and k), v columns untouched: the fused
+    QKV projection with the rotary embedding in the GEMM epilogue (bit-identical to gemm_nt + rope_)."""
+    T, Kd = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((T, N), device=x.device, dtype=BF16)
+    call("lmod_gemm_qkv_rope_bf16", ptr(x), ptr(w), ptr(out), ptr(bias), T, N, Kd, x.stride(0), w.stride(0), out.stride(0),
+         ptr(cos_t), ptr(sin_t), ptr(pos), nrot_heads * 128)
+    return out
+
+
 def gemm_swiglu(x, w_gu, act=None, gu=None, want_gu=False, m_valid=None):
     """act[.., M, I] = silu(x @ Wg^T) * (x @ Wu^T) for the fused gate-over-up weight w_gu [.., 2I, K] in ONE GEMM launch
     (SwiGLU in the epilogue).  x: [M, K] or [E, M, K] (grouped, weights [E, 2I, K] or shared [2I, K]).

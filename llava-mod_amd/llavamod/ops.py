@@ -238,8 +238,11 @@ class AttnBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, *params):
         B, S, nh, nkv, hd = spec.B, spec.S, spec.nh, spec.nkv, spec.hd
-        qkv = linear_fwd(x, spec.qkv)
-        K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
+        if K.qkv_rope_fusable(x, spec.qkv.w, nh + nkv, hd):        # rotary embedding in the QKV GEMM's epilogue (one launch)
+            qkv = K.gemm_qkv_rope(x, spec.qkv.w, spec.qkv.b, spec.cos, spec.sin, spec.pos, nh + nkv)
+        else:
+            qkv = linear_fwd(x, spec.qkv)
+            K.rope_(qkv, spec.cos, spec.sin, spec.pos, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         kv_out = getattr(spec, "kv_out", None)
         if kv_out is not None:                  # generation prefill: keep the post-RoPE keys and the values

@@ -399,6 +399,37 @@ def test_rope_fwd_bwd():
     close(gb[:, (nh + nkv) * hd:], g[:, (nh + nkv) * hd:], "rope bwd leaves V", rtol=0, afrac=0)
 
 
+@pytest.mark.parametrize("T,nh,nkv,Kd", [(1000, 4, 4, 512), (777, 6, 2, 256), (2048, 16, 16, 2048)])
+def test_fused_qkv_rope_gemm_is_bit_identical_to_gemm_plus_rope(T, nh, nkv, Kd):
+    """lmod_gemm_qkv_rope_bf16 (rotary embedding in the QKV GEMM's epilogue: rounded acc + bias swapped between neighbouring
+    wave columns through LDS, rope_kernel's roundings) == lmod_gemm_bf16_nt + lmod_rope, bit for bit: rows not a multiple of the
+    tile, GQA widths, the V columns untouched, and against the bf16 reference arithmetic of apply_rotary_pos_emb."""
+    hd = 128
+    N = (nh + 2 * nkv) * hd
+    x = rnd(T, Kd, seed=3) * 0.5
+    w = rnd(N, Kd, seed=4) * 0.05
+    b = rnd(N, seed=5)
+    cos, sin = _rope_tables(4096, hd)
+    pos = ((torch.arange(T) * 7) % 3000).to(torch.int32).to(DEV)
+    assert K.qkv_rope_fusable(x, w, nh + nkv, hd)
+    ref = K.gemm_nt(x, w, bias=b)
+    plain = ref.clone()
+    K.rope_(ref, cos, sin, pos, nh + nkv, hd)
+    out = K.gemm_qkv_rope(x, w, b, cos, sin, pos, nh + nkv)
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    assert torch.equal(out[:, (nh + nkv) * hd:], plain[:, (nh + nkv) * hd:])
+    xq = plain[:, :(nh + nkv) * hd].reshape(T, nh + nkv, hd)
+    c, s_ = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+    close(out[:, :(nh + nkv) * hd], ((xq * c) + (_rot_half(xq) * s_)).reshape(T, -1), "fused qkv rope vs bf16 reference",
+          rtol=2 ** -8, afrac=2 ** -9)
+    # without a bias, into a preallocated strided buffer
+    big = torch.zeros(T, N + 64, device=DEV, dtype=BF)
+    K.gemm_qkv_rope(x, w, None, cos, sin, pos, nh + nkv, out=big[:, :N])
+    ref2 = K.gemm_nt(x, w)
+    K.rope_(ref2, cos, sin, pos, nh + nkv, hd)
+    assert torch.equal(big[:, :N], ref2) and float(big[:, N:].abs().max()) == 0.0
+
+
 def test_swiglu_gelu_add():
     T, I = 77, 5504
     gu = rnd(T, 2 * I, seed=1)
