@@ -267,6 +267,27 @@ int lmod_dpo_loss(const float* policy_chosen, const float* policy_rejected, cons
                   float* chosen_rewards, float* rejected_rewards, float* d_policy_chosen, float* d_policy_rejected,
                   hipStream_t stream);
 
+/* ---- collectives of the data-parallel step (RCCL over xGMI; bound at run time, no link dependency) -------------------
+ * Replace what DeepSpeed's engine does for the reference around each optimizer step (train/align_trainer.py:326-434 builds it
+ * from config/dpconfig/zero2*.json: gradient reduce-scatter / all-reduce, parameter all-gather) and the two all-to-alls of
+ * deepspeed.moe.sharded_moe.MOELayer.forward (call site llava_qwen2_moe.py:536-546).  One communicator per process / GPU.
+ * The Python package drives the same exchanges through torch.distributed; these are the boundary for other hosts. */
+/* rank 0: fill the 128-byte communicator id; the host distributes it to the other ranks. */
+int lmod_comm_unique_id(void* id128);
+/* collective over all `world` ranks (current HIP device = this rank's GPU); *comm receives the handle. */
+int lmod_comm_init(void** comm, const void* id128, int rank, int world);
+int lmod_comm_destroy(void* comm);
+/* buf[0..n) <- SUM over ranks, in place.  dtype: 0 fp32, 1 bf16.  (The mean's 1/world goes into lmod_adamw_step's grad_scale.) */
+int lmod_allreduce_grads(void* comm, void* buf, long long n, int dtype, hipStream_t stream);
+/* ZeRO-2 gradient phase: span[0 .. world*n_per_rank) -> chunk `rank` of the SUM, in place at span + rank*n_per_rank. */
+int lmod_reduce_scatter_grads(void* comm, void* span, long long n_per_rank, int dtype, hipStream_t stream);
+/* ZeRO-2 parameter phase: every rank publishes its updated chunk (span + rank*n_per_rank) to all, in place. */
+int lmod_allgather_params(void* comm, void* span, long long n_per_rank, int dtype, hipStream_t stream);
+/* Expert-parallel exchange of PACKED live rows (bf16, H wide): send_rows[d] consecutive rows of `send` go to peer d, recv_rows[s]
+ * rows from peer s land consecutively in `recv` (HOST arrays of `world` counts).  One ncclSend / ncclRecv per peer in one group. */
+int lmod_moe_all_to_all(void* comm, const void* send, void* recv, const long long* send_rows, const long long* recv_rows,
+                        int H, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,14 @@ SIGNATURES = {
     "lmod_row_softmax_f32": "pqii" + "pi" + "p",
     "lmod_rowdot_masked": "pp" + "ii" + "p" + "p",
     "lmod_dpo_loss": "pppp" + "iffi" + "ppppp" + "p",
+    # collectives (csrc/comm.hip).  The three communicator life-cycle functions take no stream: call them through load().
+    "lmod_comm_unique_id": "p",
+    "lmod_comm_init": "pp" + "ii",
+    "lmod_comm_destroy": "p",
+    "lmod_allreduce_grads": "pp" + "qi" + "p",
+    "lmod_reduce_scatter_grads": "pp" + "qi" + "p",
+    "lmod_allgather_params": "pp" + "qi" + "p",
+    "lmod_moe_all_to_all": "ppp" + "pp" + "i" + "p",
 }
 _CT = {"p": _P, "i": _I, "q": _Q, "f": _F, "Q": ctypes.c_ulonglong}
 _ERR = {-1: "LMOD_EINVAL (bad pointer/shape/alignment)", -2: "LMOD_ELAUNCH (HIP launch error)",
