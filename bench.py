@@ -473,7 +473,7 @@ def main():
         gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
         traffic, traffic_note = None, "no committed PMC pass for this shape"
-        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
+        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r03_final_gemm_traffic.json", "r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
                    if os.path.exists(t)), "")
         if tp:
             tj = json.load(open(tp))
@@ -483,7 +483,7 @@ def main():
                                 f"algorithmic {tj['algorithmic_bytes'] / 1e9:.2f} GB — see profiles/{os.path.basename(tp).replace('gemm_traffic.json', 'pmc.md')}")
         out = {
             "metric": "distillation samples/sec (336px img + 2k ctx), 2B-MoE student / 7B teacher",
-            "value": round(sps, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(sps, 4), "unit": "samples/s" if args.stage == "mimic" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, seeded image/token batches)",
             "config": {"workload": ("config 2/3/5: mimic distillation (kd_lm + moe aux)" if args.stage == "mimic" else

@@ -768,6 +768,21 @@ def test_abi_error_codes_and_empty_inputs():
     with pytest.raises(RuntimeError, match="LMOD_EINVAL"):
         K.gemm_nt(rnd(8, 12, seed=83), rnd(8, 12, seed=84))             # K = 12 through the binding
     assert K.gemm_nt(a[:0], b).shape == (0, 64)                         # zero rows: allocates, launches nothing
+    # fused QKV + RoPE: the rotated block must end on a 256-column tile, N % 16, tables and positions present
+    x, w = rnd(64, 64, seed=85), rnd(512, 64, seed=86)
+    out = torch.zeros(64, 512, device=DEV, dtype=BF)
+    cos, sin = _rope_tables(16, 128)
+    pos = torch.zeros(64, device=DEV, dtype=torch.int32)
+    r = lambda rope_cols, N=512, cos_p=cos.data_ptr(), M=64: lib.lmod_gemm_qkv_rope_bf16(
+        x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, 64, 64, 64, 512, cos_p, sin.data_ptr(), pos.data_ptr(), rope_cols, s)
+    assert r(256) == 0 and r(0) == 0 and r(512) == 0
+    assert r(128) == -1 and r(768) == -1                               # not a tile multiple / past N
+    assert r(256, N=504) == -1                                          # N % 16
+    assert r(256, cos_p=None) == -1                                     # no table
+    assert r(256, M=0) == 0                                             # empty
+    # collectives: bad handles / dtypes are refused before RCCL is touched
+    assert lib.lmod_allreduce_grads(None, c.data_ptr(), 16, 0, s) == -1
+    assert lib.lmod_comm_init(None, None, 0, 1) == -1
     torch.cuda.synchronize()
 
 
