@@ -338,8 +338,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 #ifndef G256_EARLYBAR
 #define G256_EARLYBAR 0
 #endif
-//   G256_TRACE      instrumentation build: workgroup G256_TRACE_WG stamps the shader cycle counter (s_getreg SHADER_CYCLES,
-//                   20 bits, no waitcnt) at 7 points of each of the 4 phases of K tile G256_TRACE_T into one VGPR
+//   G256_DMA_SPLIT  (deep schedule) 1: the odd wave columns issue their LDS-DMA pieces BEFORE their ds_reads, the even ones after
+//                   (as before): the four waves of a row then reach the CU's one vector-memory issue port at different times
+//                   instead of queueing behind each other (a piece costs its wave 75-100 cycles of issue in the cycle trace).
+#ifndef G256_DMA_SPLIT
+#define G256_DMA_SPLIT 0
+#endif
+//   G256_TRACE      instrumentation build: workgroup G256_TRACE_WG stamps the shader cycle counter (s_memtime + lgkmcnt wait: perturbing) at 7 points of each of the 4 phases of K tile G256_TRACE_T into one VGPR
 //                   (v_writelane) and dumps it; tools/gemm_trace.py prints the per-wave timeline.
 #ifndef G256_TRACE
 #define G256_TRACE 0
@@ -586,8 +591,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #define G256_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #if G256_TRACE
   uint32_t vtrace = 0;
-#define G256_STAMP(IDX) do { if (t == G256_TRACE_T) { uint32_t c_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_SHADER_CYCLES, 0, 20)" : "=s"(c_) :: "memory"); \
-                                                      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vtrace) : "s"(c_), "n"(IDX)); } } while (0)
+  // gfx950 has no SHADER_CYCLES hwreg: s_memtime + its lgkmcnt wait (which also drains the wave's pending ds_reads: the stamps
+  // perturb the schedule they measure by that much)
+#define G256_STAMP(IDX) do { if (t == G256_TRACE_T) { unsigned long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory"); \
+                                                      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vtrace) : "s"((uint32_t)c_), "n"(IDX)); } } while (0)
 #else
 #define G256_STAMP(IDX) do { } while (0)
 #endif
@@ -655,11 +662,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // A(mh0)_0, B(nh0)_0 landed
   G256_BARRIER();
   if (G256_STAGGER && wr == 1) G256_BARRIER();
-#define G256_DSTAGE(KIND, T) do { if (!(G256_ABL & 1)) stage(KIND, T); } while (0)
+#define G256_DSTAGE(KIND, T) do { if (!(G256_ABL & 1) && !(G256_DMA_SPLIT && (wc & 1))) stage(KIND, T); } while (0)
+#define G256_DSTAGE_EARLY(KIND, T) do { if (!(G256_ABL & 1) && G256_DMA_SPLIT && (wc & 1)) stage(KIND, T); } while (0)
 #define G256_DWAIT() do { if (!(G256_ABL & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
   for (int t = 0; t < nkt; ++t) {
     // ---- P1: quadrant (mh0, nh0) ----
     { constexpr int ph_ = 0; G256_STAMP(ph_ * 8 + 0);
+    G256_DSTAGE_EARLY(3, t + 1);
     G256_RA(t, 0); G256_RB(t, 0);
     G256_STAMP(ph_ * 8 + 1);
     G256_DSTAGE(3, t + 1);                                // slot last read in P2 of tile t-1
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     G256_STAMP(ph_ * 8 + 7); }
     // ---- P2: quadrant (mh0, nh1) ----
     { constexpr int ph_ = 1; G256_STAMP(ph_ * 8 + 0);
+    G256_DSTAGE_EARLY(1, t + 1);
     G256_RB(t, 1);
     G256_STAMP(ph_ * 8 + 1);
     G256_DSTAGE(1, t + 1);                                // slot last read in P3 of tile t-1
@@ -682,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     G256_STAMP(ph_ * 8 + 7); }
     // ---- P3: quadrant (mh1, nh1) ----
     { constexpr int ph_ = 2; G256_STAMP(ph_ * 8 + 0);
+    G256_DSTAGE_EARLY(0, t + 2);
     G256_RA(t, 1);
     G256_STAMP(ph_ * 8 + 1);
     G256_DSTAGE(0, t + 2);                                // slot last read in P1 of this tile
@@ -692,6 +703,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     G256_STAMP(ph_ * 8 + 7); }
     // ---- P4: quadrant (mh1, nh0): B(nh0) fragments are still in registers ----
     { constexpr int ph_ = 3; G256_STAMP(ph_ * 8 + 0);
+    G256_DSTAGE_EARLY(2, t + 2);
     G256_STAMP(ph_ * 8 + 1);
     G256_DSTAGE(2, t + 2);                                // slot last read in P1 of this tile
     G256_STAMP(ph_ * 8 + 2);
@@ -702,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     G256_STAMP(ph_ * 8 + 7); }
   }
 #undef G256_DSTAGE
+#undef G256_DSTAGE_EARLY
 #undef G256_DWAIT
 #else
   // prologue: tile 0 in issue order A(mh0), B(nh0), B(nh1), A(mh1); first reads need the first two

@@ -23,7 +23,7 @@ for libname in sys.argv[1:]:
     assert lib.lmod_debug_gemm_trace(buf.ctypes.data_as(P)) == 0
     st = buf.reshape(8, 64)[:, :32].astype(np.int64)
     base = st.min()
-    st = (st - base) % (1 << 20)
+    st = (st - base) % (1 << 32)
     print(f"== {libname}: cycles relative to the earliest stamp of the traced K tile (one workgroup, 8 waves; wr = wave>>2)")
     print("wave | " + " | ".join(f"P{p + 1}.{NAMES[k]}" for p in range(4) for k in range(8)))
     for w in range(8):
