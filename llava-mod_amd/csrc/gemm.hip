@@ -328,6 +328,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
 //                       P2: read B(nh1)         | prefetch A(mh1) of t+1      P4: no reads    | prefetch B(nh0) of t+2
 //                   Issue order = consumption order (vmcnt retires in order), 4 half-tiles (8 loads per thread) stay in
 //                   flight across the counted waits (vmcnt(8)) instead of 2.
+//                   2: deep + the ds_reads of the NEXT phase issued under this phase's MFMAs (after the 4th of 16) into a second A
+//                   fragment set (+32 VGPRs): B(nh1) under P1, A(mh1) under P2, A(mh0) of tile t+1 under P3; only B(nh0) is still
+//                   read in a reading interval.  Data read under the MFMAs of phase p must have been waited for by EVERY wave one
+//                   barrier earlier than before (the two wave rows run one barrier apart): waits are vmcnt(6), 3 half-tiles in flight.
 #ifndef G256_DEEP
 #define G256_DEEP 1
 #endif
@@ -541,8 +545,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const int ph0 = ((lane >> 4) ^ (lane & 7)) * 16;
   const int ph1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
 
-  bf16x8 af[4][2], bfr2[2][2][2];      // bfr2[nh]: fragments of B half-tile nh (the classic schedule only uses set 0)
+  bf16x8 af2[2][4][2], bfr2[2][2][2];  // bfr2[nh] / af2[mh]: fragments of B half-tile nh / A half-tile mh (classic: set 0 only; deep: both B sets; deep 2: both A sets too)
 #define BFR(NH) bfr2[G256_DEEP ? (NH) : 0]
+#define AFR(MH) af2[G256_DEEP == 2 ? (MH) : 0]
   // MODE 2: per-lane pieces of the transposing read (see the kernel header): k row g*8 + (i>>2) (+4 for the second
   // half of the fragment, +32 per k-step), 8 bytes at (i&3)*8 inside the 32-byte block (m-tile index ^ key)
   const int trk = ((lane >> 4) * 8 + (li >> 2)) * 256 + (li & 3) * 8;
@@ -559,16 +564,16 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       const char* sl = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT;
 #pragma unroll
       for (int ml = 0; ml < 4; ++ml) {
-        af[ml][0] = read_tr16(sl, wr * 4 + ml, 0);
-        af[ml][1] = read_tr16(sl, wr * 4 + ml, 1);
+        AFR(mh)[ml][0] = read_tr16(sl, wr * 4 + ml, 0);
+        AFR(mh)[ml][1] = read_tr16(sl, wr * 4 + ml, 1);
       }
       return;
     }
     const char* s = smem + (t & 1) * (4 * G256_SLOT) + mh * G256_SLOT + wr * 8192 + rdrow;
 #pragma unroll
     for (int ml = 0; ml < 4; ++ml) {
-      af[ml][0] = *(const bf16x8*)(s + ml * 2048 + ph0);
-      af[ml][1] = *(const bf16x8*)(s + ml * 2048 + ph1);
+      AFR(mh)[ml][0] = *(const bf16x8*)(s + ml * 2048 + ph0);
+      AFR(mh)[ml][1] = *(const bf16x8*)(s + ml * 2048 + ph1);
     }
   };
   auto readB = [&](int t, int nh) {
@@ -617,13 +622,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #define G256_MFMA_BODY(MH, NH, KK, MLLO, MLHI)                                                              \
       _Pragma("unroll") for (int ml = (MLLO); ml < (MLHI); ++ml)                                            \
         acc32[(MH) * 2 + (ml & 1)][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                           \
-            BFR(NH)[ml >> 1][KK], af[ml][KK], acc32[(MH) * 2 + (ml & 1)][NH], 0, 0, 0);
+            BFR(NH)[ml >> 1][KK], AFR(MH)[ml][KK], acc32[(MH) * 2 + (ml & 1)][NH], 0, 0, 0);
 #else
 #define G256_MFMA_BODY(MH, NH, KK, MLLO, MLHI)                                                              \
       _Pragma("unroll") for (int ml = (MLLO); ml < (MLHI); ++ml)                                            \
         _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                    \
           acc[(MH) * 4 + ml][(NH) * 2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-              BFR(NH)[nl][KK], af[ml][KK], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);
+              BFR(NH)[nl][KK], AFR(MH)[ml][KK], acc[(MH) * 4 + ml][(NH) * 2 + nl], 0, 0, 0);
 #endif
 #define G256_MFMA(MH, NH, KIND, T)                                                                          \
   do {                                                                                                      \
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     if (G256_PRIO) __builtin_amdgcn_s_setprio(1);                                                           \
     if (!(G256_ABL & 8)) {                                                                                  \
       G256_MFMA_BODY(MH, NH, 0, 0, 2)                                                                       \
+      if (G256_DEEP == 2) { __builtin_amdgcn_sched_barrier(0); G256_UNDER_MFMA(MH, NH); __builtin_amdgcn_sched_barrier(0); } \
       if (G256_STAGE_POS == 3) { __builtin_amdgcn_sched_barrier(0); G256_LOOPSTAGE(3, KIND, T, 0, 1); __builtin_amdgcn_sched_barrier(0); } \
       G256_MFMA_BODY(MH, NH, 0, 2, 4)                                                                       \
       if (G256_STAGE_POS == 2) { __builtin_amdgcn_sched_barrier(0); G256_LOOPSTAGE(2, KIND, T, 0, 2); __builtin_amdgcn_sched_barrier(0); } \
@@ -656,7 +662,50 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #define G256_RA(T, MH) do { if (!(G256_ABL & 2)) readA(T, MH); } while (0)
 #define G256_RB(T, NH) do { if (!(G256_ABL & 2)) readB(T, NH); } while (0)
 
-#if G256_DEEP
+#if G256_DEEP == 2
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // all of tile 0 landed
+  G256_BARRIER();
+  readA(0, 0);                                            // A(mh0)_0: in the steady state it is read under P3 of the previous tile
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  G256_BARRIER();
+  if (G256_STAGGER && wr == 1) G256_BARRIER();
+#define G256_DSTAGE(KIND, T) do { if (!(G256_ABL & 1)) stage(KIND, T); } while (0)
+#define G256_DWAIT() do { if (!(G256_ABL & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
+  for (int t = 0; t < nkt; ++t) {
+    // ---- P1: quadrant (mh0, nh0); under its MFMAs: read B(nh1)_t ----
+    G256_RB(t, 0);
+    G256_DSTAGE(3, t + 1);
+    G256_DWAIT();                                         // retires A(mh1)_t (read under P2's MFMAs)
+    G256_BARRIER1();
+#define G256_UNDER_MFMA(MH, NH) G256_RB(t, 1)
+    G256_MFMA(0, 0, 0, 0);
+#undef G256_UNDER_MFMA
+    // ---- P2: quadrant (mh0, nh1); under its MFMAs: read A(mh1)_t ----
+    G256_DSTAGE(1, t + 1);
+    G256_DWAIT();                                         // retires A(mh0)_{t+1} (read under P3's MFMAs)
+    G256_BARRIER1();
+#define G256_UNDER_MFMA(MH, NH) G256_RA(t, 1)
+    G256_MFMA(0, 1, 0, 0);
+#undef G256_UNDER_MFMA
+    // ---- P3: quadrant (mh1, nh1); under its MFMAs: read A(mh0)_{t+1} ----
+    G256_DSTAGE(0, t + 2);
+    G256_BARRIER1();
+#define G256_UNDER_MFMA(MH, NH) G256_RA(t + 1, 0)
+    G256_MFMA(1, 1, 0, 0);
+#undef G256_UNDER_MFMA
+    // ---- P4: quadrant (mh1, nh0) ----
+    G256_DSTAGE(2, t + 2);
+    G256_DWAIT();                                         // retires B(nh0)_{t+1} (read in the next P1) and B(nh1)_{t+1} (read under its MFMAs)
+    G256_BARRIER1();
+#define G256_UNDER_MFMA(MH, NH) do { } while (0)
+    G256_MFMA(1, 0, 0, 0);
+#undef G256_UNDER_MFMA
+  }
+#undef G256_DSTAGE
+#undef G256_DWAIT
+#elif G256_DEEP
+#define G256_UNDER_MFMA(MH, NH) do { } while (0)
   // deep-prefetch schedule (see the knob list): prologue = what the steady state would have issued before P1 of tile 0
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // A(mh0)_0, B(nh0)_0 landed
@@ -717,6 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #undef G256_DSTAGE_EARLY
 #undef G256_DWAIT
 #else
+#define G256_UNDER_MFMA(MH, NH) do { } while (0)
   // prologue: tile 0 in issue order A(mh0), B(nh0), B(nh1), A(mh1); first reads need the first two
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -798,6 +848,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #undef G256_MFMA
 #undef G256_BARRIER
 #undef BFR
+#undef AFR
+#if G256_DEEP != 2
+#undef G256_UNDER_MFMA
+#endif
 #undef G256_STAMP
 
   // ---- epilogue: lane holds, for each mt, row (lane&15) and 16 contiguous columns ----
