@@ -164,6 +164,13 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S, int nh, int nkv,
                   int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
                   int causal, hipStream_t stream);
+/* lmod_attn_bwd with the gradient map of the rotary embedding (apply_rotary_pos_emb, qwen2/modeling_qwen2.py:146-171) applied to dQ and
+ * dK in the backward kernels' epilogues, head dim 128 only: bit-identical to lmod_attn_bwd followed by lmod_rope(backward = 1) on the
+ * q and k column blocks.  cos_t / sin_t: [max_pos x 128] bf16, pos: int32 per token row. */
+int lmod_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                       float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                       int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                       float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, hipStream_t stream);
 
 /* Single-query attention against a KV cache (generation: llava_qwen2_moe.py:453-473 prepare_inputs_for_generation,
  * qwen2/modeling_qwen2.py:290-309 with q_len 1).  q [B, ldq] (head h at column h*hd), caches [B, smax, ld_cache] (kv head

@@ -682,11 +682,14 @@ static bool bwd_generic() {      // LMOD_ATTN_BWD=1: hd-128 backward through the
   return v;
 }
 
-int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
-                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
-                  float scale, int causal, hipStream_t stream) {
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                         float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                         int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                         float scale, int causal, const void* rope_cos, const void* rope_sin, const int* rope_pos,
+                         hipStream_t stream) {
   if (!Q || !K || !V || !O || !dO || !lse || !delta_ws || !dQ || !dK || !dV) return LMOD_EINVAL;
+  if (rope_pos && (!rope_cos || !rope_sin)) return LMOD_EINVAL;
+  if (rope_pos && (hd != 128 || bwd_generic())) return LMOD_EUNSUPPORTED;     // fused only in the hd-128 kernels (attn_bwd2.hip)
   int rc = check_common(B, S, nh, nkv, hd, ldq, ldk, ldv);
   if (rc) return rc;
   if ((ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7) || ldo < nh * hd || lddo < nh * hd ||
@@ -698,6 +701,7 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale;
+  p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin; p.rope_pos = rope_pos;
   if (cu_seqlens && (hd != 128 || seqlens)) return LMOD_EUNSUPPORTED;
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
@@ -724,6 +728,26 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
   else LAUNCH_BWD(64, false);
 #undef LAUNCH_BWD
   return lmod_launch_status();
+}
+
+int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                  float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                  int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                  float scale, int causal, hipStream_t stream) {
+  return attn_bwd_impl(Q, K, V, O, dO, lse, delta_ws, dQ, dK, dV, seqlens, cu_seqlens, B, S, nh, nkv, hd, ldq, ldk, ldv, ldo, lddo,
+                       lddq, lddk, lddv, scale, causal, nullptr, nullptr, nullptr, stream);
+}
+
+// lmod_attn_bwd with the gradient map of the rotary embedding applied to dQ and dK before they are stored (head dim 128):
+// what autograd does for apply_rotary_pos_emb (qwen2/modeling_qwen2.py:146-171) after the attention backward, without the extra
+// pass over the d(QKV) buffer.  pos: int32 per token row of Q / K (the same indexing as dQ / dK), tables [max_pos, 128] bf16.
+int lmod_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                       float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                       int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                       float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, hipStream_t stream) {
+  if (!cos_t || !sin_t || !pos) return LMOD_EINVAL;
+  return attn_bwd_impl(Q, K, V, O, dO, lse, delta_ws, dQ, dK, dV, seqlens, cu_seqlens, B, S, nh, nkv, hd, ldq, ldk, ldv, ldo, lddo,
+                       lddq, lddk, lddv, scale, causal, cos_t, sin_t, pos, stream);
 }
 
 }  // extern "C"

@@ -66,6 +66,31 @@ __device__ __forceinline__ void store_strip(bf16_t* dst, const float mul) {   //
   *(u32x4*)(dst) = w0;
   *(u32x4*)(dst + 8) = w1;
 }
+// RoPE backward on the strip pair (N1: features f .. f+15 < 64, N2: the same + 64) of this lane's row, in registers: the lane holds both
+// halves of every rotate_half pair.  g = the bf16-rounded gradients the plain epilogue would store; then rope_kernel's backward
+// arithmetic (rowops.hip): dx1 = g1*cos1 + g2*sin2, dx2 = g2*cos2 - g1*sin1, each product rounded to bf16 — bit-identical to
+// store + lmod_rope(backward).  cp / sp: cos / sin rows of the token's position, at feature f.
+template <int N1, int N2>
+__device__ __forceinline__ void store_pair_rope(bf16_t* dst, const float mul, const bf16_t* cp, const bf16_t* sp) {
+  float v1[16], v2[16];
+  acc_read16<N1>(v1);
+  acc_read16<N2>(v2);
+#pragma unroll
+  for (int hx = 0; hx < 2; ++hx) {
+    const u32x4 c1 = *(const u32x4*)(cp + hx * 8), c2 = *(const u32x4*)(cp + 64 + hx * 8);
+    const u32x4 s1 = *(const u32x4*)(sp + hx * 8), s2 = *(const u32x4*)(sp + 64 + hx * 8);
+    u32x4 o1, o2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a0 = bfround(v1[hx * 8 + 2 * k] * mul), a1 = bfround(v1[hx * 8 + 2 * k + 1] * mul);
+      const float b0 = bfround(v2[hx * 8 + 2 * k] * mul), b1 = bfround(v2[hx * 8 + 2 * k + 1] * mul);
+      o1[k] = pack2bf(bfround(a0 * bflo(c1[k])) + bfround(b0 * bflo(s2[k])), bfround(a1 * bfhi(c1[k])) + bfround(b1 * bfhi(s2[k])));
+      o2[k] = pack2bf(bfround(b0 * bflo(c2[k])) - bfround(a0 * bflo(s1[k])), bfround(b1 * bfhi(c2[k])) - bfround(a1 * bfhi(s1[k])));
+    }
+    *(u32x4*)(dst + hx * 8) = o1;
+    *(u32x4*)(dst + 64 + hx * 8) = o2;
+  }
+}
 template <int I> using IC = std::integral_constant<int, I>;
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
@@ -492,16 +517,28 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     if constexpr (DKV) {
       bf16_t* dk = p.dK + (tok0 + row) * p.lddk + ho * 128 + hi * 16;
       bf16_t* dv = p.dV + (tok0 + row) * p.lddv + ho * 128 + hi * 16;
+      const bf16_t* cp = nullptr; const bf16_t* sp = nullptr;
+      if (p.rope_pos) {
+        const long long ro = (long long)p.rope_pos[tok0 + row] * 128 + hi * 16;
+        cp = p.rope_cos + ro; sp = p.rope_sin + ro;
+      }
       if (os == 0) {
-        store_strip<0>(dk, p.scale); store_strip<1>(dk + 32, p.scale); store_strip<2>(dk + 64, p.scale); store_strip<3>(dk + 96, p.scale);
+        if (cp) { store_pair_rope<0, 2>(dk, p.scale, cp, sp); store_pair_rope<1, 3>(dk + 32, p.scale, cp + 32, sp + 32); }
+        else { store_strip<0>(dk, p.scale); store_strip<1>(dk + 32, p.scale); store_strip<2>(dk + 64, p.scale); store_strip<3>(dk + 96, p.scale); }
         store_strip<8>(dv, 1.f); store_strip<9>(dv + 32, 1.f); store_strip<10>(dv + 64, 1.f); store_strip<11>(dv + 96, 1.f);
       } else {
-        store_strip<4>(dk, p.scale); store_strip<5>(dk + 32, p.scale); store_strip<6>(dk + 64, p.scale); store_strip<7>(dk + 96, p.scale);
+        if (cp) { store_pair_rope<4, 6>(dk, p.scale, cp, sp); store_pair_rope<5, 7>(dk + 32, p.scale, cp + 32, sp + 32); }
+        else { store_strip<4>(dk, p.scale); store_strip<5>(dk + 32, p.scale); store_strip<6>(dk + 64, p.scale); store_strip<7>(dk + 96, p.scale); }
         store_strip<12>(dv, 1.f); store_strip<13>(dv + 32, 1.f); store_strip<14>(dv + 64, 1.f); store_strip<15>(dv + 96, 1.f);
       }
     } else {
       bf16_t* dq = p.dQ + (tok0 + row) * p.lddq + ho * 128 + hi * 16;
-      if (os == 0) { store_strip<0>(dq, p.scale); store_strip<1>(dq + 32, p.scale); store_strip<2>(dq + 64, p.scale); store_strip<3>(dq + 96, p.scale); }
+      if (p.rope_pos) {
+        const long long ro = (long long)p.rope_pos[tok0 + row] * 128 + hi * 16;
+        const bf16_t* cp = p.rope_cos + ro; const bf16_t* sp = p.rope_sin + ro;
+        if (os == 0) { store_pair_rope<0, 2>(dq, p.scale, cp, sp); store_pair_rope<1, 3>(dq + 32, p.scale, cp + 32, sp + 32); }
+        else { store_pair_rope<4, 6>(dq, p.scale, cp, sp); store_pair_rope<5, 7>(dq + 32, p.scale, cp + 32, sp + 32); }
+      } else if (os == 0) { store_strip<0>(dq, p.scale); store_strip<1>(dq + 32, p.scale); store_strip<2>(dq + 64, p.scale); store_strip<3>(dq + 96, p.scale); }
       else { store_strip<4>(dq, p.scale); store_strip<5>(dq + 32, p.scale); store_strip<6>(dq + 64, p.scale); store_strip<7>(dq + 96, p.scale); }
     }
   }

@@ -21,6 +21,8 @@ struct AttnP {
   int B, S, nh, group;           // group = nh / nkv
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   float scale;
+  // lmod_attn_bwd_rope: the rotary embedding's gradient map applied to dQ / dK in the backward kernels' epilogues (hd 128)
+  const bf16_t* rope_cos; const bf16_t* rope_sin; const int* rope_pos;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;

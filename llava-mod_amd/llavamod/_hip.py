@@ -41,6 +41,7 @@ SIGNATURES = {
     "lmod_cast_f32_bf16": "pp" + "qi" + "p",
     "lmod_attn_fwd": "ppppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
+    "lmod_attn_bwd_rope": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "ppp" + "p",
     "lmod_splice_count": "pp" + "iiii" + "pp" + "p",
     "lmod_splice_fill": "ppp" + "iiii" + "pp" + "pppp" + "p",
     "lmod_lossplan_count": "p" + "iiiii" + "p" + "p",

@@ -288,11 +288,22 @@ def attn_fwd(q, k, v, B, S, nh, nkv, hd, scale, causal, seqlens=None, want_lse=T
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None, cu=None):
+def attn_bwd_rope_fusable(hd):
+    """lmod_attn_bwd_rope exists in the hd-128 kernels of attn_bwd2.hip only (not in the generic LMOD_ATTN_BWD=1 path)."""
+    import os
+    return hd == 128 and os.environ.get("LMOD_ATTN_BWD") != "1"
+
+
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None, cu=None, rope=None):
+    """rope = (cos_t, sin_t, pos): also apply the rotary embedding's gradient map to dq / dk in the kernels' epilogues."""
     delta = torch.empty((B, nh, S), device=q.device, dtype=torch.float32)
-    call("lmod_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-         ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
-         dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
+    args = (ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+            ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+            dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
+    if rope is None:
+        call("lmod_attn_bwd", *args)
+    else:
+        call("lmod_attn_bwd_rope", *args, ptr(rope[0]), ptr(rope[1]), ptr(rope[2]))
     return dq, dk, dv
 
 

@@ -276,10 +276,12 @@ class AttnBlock(torch.autograd.Function):
             do = K.gather_rows(do, None, sp.inv_rows, do.shape[1])
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        fused = K.attn_bwd_rope_fusable(hd)       # RoPE's gradient map in the backward kernels' epilogues (no pass over dqkv)
         K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
                    dqkv[:, (nh + nkv) * hd:], sp.B, sp.S, nh, nkv, hd, sp.scale, True, sp.seqlens,
-                   cu=getattr(sp, "cu", None))
-        K.rope_(dqkv, sp.cos, sp.sin, sp.pos, nh + nkv, hd, backward=True)
+                   cu=getattr(sp, "cu", None), rope=(sp.cos, sp.sin, sp.pos) if fused else None)
+        if not fused:
+            K.rope_(dqkv, sp.cos, sp.sin, sp.pos, nh + nkv, hd, backward=True)
         dx = linear_dgrad(dqkv, sp.qkv)
         if sp.qkv.requires_grad:
             linear_wgrad(dqkv, x, sp.qkv)

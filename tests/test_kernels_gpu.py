@@ -399,6 +399,34 @@ def test_rope_fwd_bwd():
     close(gb[:, (nh + nkv) * hd:], g[:, (nh + nkv) * hd:], "rope bwd leaves V", rtol=0, afrac=0)
 
 
+@pytest.mark.parametrize("B,S,nh,nkv,causal,ragged", [(2, 300, 4, 2, True, False), (1, 1100, 4, 1, True, False),
+                                                       (2, 520, 2, 2, False, True), (3, 257, 3, 3, True, True)])
+def test_attn_bwd_with_fused_rope_is_bit_identical_to_bwd_plus_rope(B, S, nh, nkv, causal, ragged):
+    """lmod_attn_bwd_rope (the rotary embedding's gradient map applied to dQ / dK in the hd-128 backward kernels' epilogues, where a
+    lane holds both halves of every rotate_half pair) == lmod_attn_bwd followed by lmod_rope(backward) on the d(QKV) buffer, bit for
+    bit: causal / non-causal, GQA, ragged key masks, odd lengths, per-sample positions; dV untouched."""
+    hd = 128
+    ld = (nh + 2 * nkv) * hd
+    qkv = rnd(B * S, ld, seed=S + 1, scale=1.0)
+    q2, k2, v2 = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    seqlens = torch.tensor([S - 17, max(1, S // 3), S][:B], dtype=torch.int32, device=DEV) if ragged else None
+    scale = 1.0 / math.sqrt(hd)
+    o, lse = K.attn_fwd(q2, k2, v2, B, S, nh, nkv, hd, scale, causal, seqlens)
+    do = rnd(B * S, nh * hd, seed=S + 2)
+    cos, sin = _rope_tables(4096, hd, theta=1e6)
+    pos = ((torch.arange(B * S) * 3) % 2500).to(torch.int32).to(DEV)
+    ref = torch.zeros(B * S, ld, device=DEV, dtype=BF)
+    K.attn_bwd(q2, k2, v2, o, do, lse, ref[:, :nh * hd], ref[:, nh * hd:(nh + nkv) * hd], ref[:, (nh + nkv) * hd:], B, S, nh, nkv, hd,
+               scale, causal, seqlens)
+    K.rope_(ref, cos, sin, pos, nh + nkv, hd, backward=True)
+    out = torch.zeros(B * S, ld, device=DEV, dtype=BF)
+    assert K.attn_bwd_rope_fusable(hd)
+    K.attn_bwd(q2, k2, v2, o, do, lse, out[:, :nh * hd], out[:, nh * hd:(nh + nkv) * hd], out[:, (nh + nkv) * hd:], B, S, nh, nkv, hd,
+               scale, causal, seqlens, rope=(cos, sin, pos))
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    assert float(out.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("T,nh,nkv,Kd", [(1000, 4, 4, 512), (777, 6, 2, 256), (2048, 16, 16, 2048)])
 def test_fused_qkv_rope_gemm_is_bit_identical_to_gemm_plus_rope(T, nh, nkv, Kd):
     """lmod_gemm_qkv_rope_bf16 (rotary embedding in the QKV GEMM's epilogue: rounded acc + bias swapped between neighbouring
