@@ -246,23 +246,43 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         emb = K.gather_rows(self.model.embed_tokens.weight, None, tokens.contiguous(), self.model.embed_tokens.weight.shape[1])
         return ops.linear_fwd(self.model.forward_decode(emb, cache), self.head())
 
+    @staticmethod
+    def _sample(logits, temperature, top_k, top_p, gen):
+        """Next token per row from bf16 logits [B, V] — HF's sampling warpers (temperature, top-k, nucleus) in that order, then
+        one multinomial draw.  O(B x V) host-glue torch math on B rows (B = number of sequences being generated)."""
+        x = logits.float() / max(float(temperature), 1e-6)
+        if top_k is not None and 0 < top_k < x.shape[-1]:
+            kth = torch.topk(x, top_k, dim=-1).values[:, -1:]
+            x = x.masked_fill(x < kth, float("-inf"))
+        if top_p is not None and top_p < 1.0:
+            sv, si = torch.sort(x, dim=-1, descending=True)
+            cp = torch.softmax(sv, dim=-1).cumsum(-1)
+            drop = cp - torch.softmax(sv, dim=-1) > top_p          # keep the smallest prefix whose mass reaches top_p
+            sv = sv.masked_fill(drop, float("-inf"))
+            x = torch.full_like(x, float("-inf")).scatter(-1, si, sv)
+        return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=gen).squeeze(-1).to(torch.int32)
+
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, images=None, max_new_tokens=16, eos_token_id=None,
-                 pad_token_id=None, do_sample=False, **kwargs):
-        """Greedy generation with a KV cache (the reference's eval path calls HF `generate` on the Eval model,
-        llava_qwen2_moe.py:629-681).  Right-padded prompts: every sample continues from its own length.  Returns the
-        NEW tokens [B, <= max_new_tokens] (int64; positions after a sample's EOS hold pad_token_id)."""
-        if do_sample:
-            raise NotImplementedError("sampling is not on this path: greedy decoding only")
+                 pad_token_id=None, do_sample=False, temperature=1.0, top_k=None, top_p=None, seed=None, **kwargs):
+        """Generation with a KV cache (the reference's eval path calls HF `generate` on the Eval model,
+        llava_qwen2_moe.py:629-681; its serving code passes do_sample / temperature / top_p).  Greedy by default; do_sample=True
+        draws from the temperature / top-k / top-p filtered distribution (`seed` makes the draw reproducible).  Right-padded
+        prompts: every sample continues from its own length.  Returns the NEW tokens [B, <= max_new_tokens] (int64; positions
+        after a sample's EOS hold pad_token_id)."""
         was_training = self.training
         self.eval()
         cache, logits = self._prefill(input_ids, attention_mask, images, max_new_tokens)
         B = logits.shape[0]
         pad = eos_token_id if pad_token_id is None else pad_token_id
         done = torch.zeros(B, dtype=torch.bool, device=logits.device)
+        gen = None
+        if do_sample:
+            gen = torch.Generator(device=logits.device)
+            gen.manual_seed(int(seed) if seed is not None else torch.seed() & 0x7FFFFFFF)
         out = []
         for step in range(max_new_tokens):
-            nxt = K.row_argmax(logits)
+            nxt = self._sample(logits, temperature, top_k, top_p, gen) if do_sample else K.row_argmax(logits)
             tok = nxt.long()
             if eos_token_id is not None:
                 tok = torch.where(done, torch.full_like(tok, pad if pad is not None else 0), tok)

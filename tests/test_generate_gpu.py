@@ -131,3 +131,35 @@ def test_save_pretrained_from_pretrained_roundtrip(tmp_path):
     assert not any(p.requires_grad for p in s2.parameters())           # Eval: frozen
     new = s2.generate(**pr, max_new_tokens=3)
     assert new.shape == (pr["input_ids"].shape[0], 3)
+
+
+def test_sampling_generate_and_padding_contract():
+    """do_sample: the temperature / top-k / top-p warpers in HF's order over the KV-cache decode loop — top_k = 1 is greedy, a seed makes
+    the draw reproducible, different seeds differ, every sampled token lies inside the nucleus; and the prefill refuses a left-padded
+    prompt (the cache is addressed as b*S + len - 1: right padding only, the reference's `padding_side="right"`)."""
+    _, teacher = _pair()
+    p = _prompt()
+    greedy = teacher.generate(**p, max_new_tokens=6)
+    top1 = teacher.generate(**p, max_new_tokens=6, do_sample=True, top_k=1, seed=3)
+    assert torch.equal(greedy, top1)
+    a = teacher.generate(**p, max_new_tokens=6, do_sample=True, temperature=1.5, top_p=0.9, seed=11)
+    b = teacher.generate(**p, max_new_tokens=6, do_sample=True, temperature=1.5, top_p=0.9, seed=11)
+    c = teacher.generate(**p, max_new_tokens=6, do_sample=True, temperature=1.5, top_p=0.9, seed=12)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # the first sampled token lies in the top-p nucleus of the prefill distribution
+    _, logits = teacher._prefill(p["input_ids"], p["attention_mask"], p["images"], 1)
+    pr = torch.softmax(logits.float() / 1.5, -1)
+    sv, si = torch.sort(pr, -1, descending=True)
+    keep = (sv.cumsum(-1) - sv) <= 0.9
+    for bi in range(a.shape[0]):
+        assert int(a[bi, 0]) in set(si[bi][keep[bi]].tolist())
+    # text-only prompts go into the cache as they are: left padding is refused (with images the splice strips the pads by mask
+    # and re-pads on the right itself, llava_arch.py:228-230,309-318)
+    ids = p["input_ids"].clamp_min(0)
+    am = torch.ones_like(ids, dtype=torch.bool)
+    am[1, :3] = False
+    with pytest.raises(ValueError, match="RIGHT-padded"):
+        teacher.generate(input_ids=ids, attention_mask=am, max_new_tokens=2)
+    am2 = torch.ones_like(ids, dtype=torch.bool)
+    am2[1, -3:] = False
+    assert teacher.generate(input_ids=ids, attention_mask=am2, max_new_tokens=2).shape == (ids.shape[0], 2)
