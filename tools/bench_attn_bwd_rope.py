@@ -18,7 +18,9 @@ def plain(): K.attn_bwd(q, k, v, o, do, lse, d[:, :nh * hd], d[:, nh * hd:2 * nh
 def two():
     plain(); K.rope_(d, cos, sin, pos, 2 * nh, hd, backward=True)
 def fused(): K.attn_bwd(q, k, v, o, do, lse, d[:, :nh * hd], d[:, nh * hd:2 * nh * hd], d[:, 2 * nh * hd:], B, S, nh, nh, hd, sc, True, rope=(cos, sin, pos))
-arms = [("bwd alone", plain), ("bwd + rope kernel", two)] + ([("bwd with fused rope", fused)] if hasattr(K._lib_check() if hasattr(K, "_lib_check") else None, "x") or "bwdhead" not in os.environ.get("LMOD_HIP_LIB", "") else [])
+arms = [("bwd alone", plain), ("bwd + rope kernel", two)]
+if "lmod_attn_bwd_rope" in __import__("llavamod._hip", fromlist=["x"]).SIGNATURES and "bwdhead" not in os.environ.get("LMOD_HIP_LIB", ""):
+    arms.append(("bwd with fused rope", fused))       # (an older build loaded through LMOD_HIP_LIB has no such entry point)
 for rnd in range(2):
     for name, f in arms:
         for _ in range(5): f()
