@@ -396,7 +396,8 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
   constexpr bool AK = (MODE == 2), BK = (MODE == 2 || MODE == 3);      // operand stored reduction-major?
-  constexpr bool SPLIT_OK = (MODE == 0 || MODE == 3);
+  constexpr bool PLAIN = (MODE == 0 || MODE == 6);   // 6 = 0 with the fp32 read-modify-write epilogue in two batches (below)
+  constexpr bool SPLIT_OK = (PLAIN || MODE == 3);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     split = bz; bz = 0; id -= split * tpb;
   }
   int r = id - bz * tpb;
-  if (MODE == 0 && p.k_valid && !p.m_valid && p.batch > 1 && p.batch <= GEMM_MAX_GROUPS && p.splitk <= 1 && !(tpb & 7)) {
+  if (PLAIN && p.k_valid && !p.m_valid && p.batch > 1 && p.batch <= GEMM_MAX_GROUPS && p.splitk <= 1 && !(tpb & 7)) {
     // Batched weight gradients with a different live reduction length per batch (MoE experts: k_valid = routed rows).
     // The generic mapping hands each XCD ONE contiguous chunk of (batch, tile) ids, i.e. whole experts: with routed-row
     // counts of 9k / 12k / 20k / 24k the XCDs holding the long experts ran 2.7x longer than the others (880 TF against
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       if constexpr (BK) {
         const int nb = (mp >> 5) * 64 + h * 32 + (mp & 31);            // B: tile column (natural order)
         voB[h][j] = (nb < rowsB) ? (uint32_t)((krow * p.ldb + nb) * 2) : GEMM_OOB;
-      } else if (MODE == 0 || MODE == 4 || MODE == 5) {
+      } else if (PLAIN || MODE == 4 || MODE == 5) {
         const int nloc = wcs * 64 + (ii >> 2) * 16 + (h * 2 + ntl) * 4 + (ii & 3);   // B: permuted tile column
         voB[h][j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       } else {       // half h = gate (0) / up (1) rows of the same 128 output columns
@@ -920,7 +921,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     const int cb = col0 + wc * 64 + g * 16;
     float bia[16];
 #pragma unroll
-    for (int x = 0; x < 16; ++x) bia[x] = (p.bias && cb + x < p.N) ? bf2f(p.bias[min(cb + x, p.N - 1)]) : 0.f;
+    for (int x = 0; x < 16; ++x) bia[x] = 0.f;
+    if (p.bias) {           // clamped, unconditional loads: 16 in flight, ONE wait (a per-element condition made each its own round trip)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const float bv = bf2f(p.bias[min(cb + x, p.N - 1)]);
+        bia[x] = (cb + x < p.N) ? bv : 0.f;
+      }
+    }
     u32x4 own[8][2];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -942,31 +950,60 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         for (int hx = 0; hx < 2; ++hx) *(u32x4*)(smem + ((wave * 8 + mt) * 2 + hx) * 1024 + lane * 16) = own[mt][hx];
       __syncthreads();
       const int fh = (wc & 1) * 64 + g * 16;         // feature of v[0] inside its head
+      if (cb >= p.N) return;                         // (no barrier below)
+      // Memory order as in the MODE 4 epilogue: row tile by row tile (position -> cos/sin -> store) every tile was two
+      // exposed round trips behind the previous tile's stores.  Here: all 8 positions, then cos/sin of row tiles 0-3,
+      // compute, cos/sin of 4-7, THEN the stores of 0-3, compute, stores of 4-7.  Rows past Mv read a clamped row.
+      auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+      int ps[8];
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        const int row = row0 + wr * 128 + mt * 16 + li;
-        if (row >= Mv || cb >= p.N) continue;
-        const int ps = p.rope_pos[(long long)bz * p.M + row];
-        const bf16_t* cp = p.rope_cos + (long long)ps * 128 + fh;
-        const bf16_t* sp = p.rope_sin + (long long)ps * 128 + fh;
-        u32x4 o[2];
+      for (int mt = 0; mt < 8; ++mt) ps[mt] = p.rope_pos[(long long)bz * p.M + min(rowof(mt), p.M - 1)];
+      u32x4 CC[2][4][2], SS[2][4][2];
+      auto ld = [&](const int b4) {
 #pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-          const u32x4 pr = *(const u32x4*)(smem + (((wave ^ 1) * 8 + mt) * 2 + hx) * 1024 + lane * 16);
-          const u32x4 cc = *(const u32x4*)(cp + hx * 8), ss = *(const u32x4*)(sp + hx * 8);
+        for (int m = 0; m < 4; ++m) {
+          const bf16_t* cp = p.rope_cos + (long long)ps[b4 * 4 + m] * 128 + fh;
+          const bf16_t* sp = p.rope_sin + (long long)ps[b4 * 4 + m] * 128 + fh;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float x0 = bflo(own[mt][hx][k]), x1 = bfhi(own[mt][hx][k]);
-            float y0 = bflo(pr[k]), y1 = bfhi(pr[k]);
-            if (!(wc & 1)) { y0 = -y0; y1 = -y1; }    // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin
-            o[hx][k] = pack2bf(bfround(x0 * bflo(cc[k])) + bfround(y0 * bflo(ss[k])),
-                               bfround(x1 * bfhi(cc[k])) + bfround(y1 * bfhi(ss[k])));
+          for (int hx = 0; hx < 2; ++hx) { CC[b4][m][hx] = *(const u32x4*)(cp + hx * 8); SS[b4][m][hx] = *(const u32x4*)(sp + hx * 8); }
+        }
+      };
+      auto cmp = [&](const int b4) {                 // result in CC
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int mt = b4 * 4 + m;
+#pragma unroll
+          for (int hx = 0; hx < 2; ++hx) {
+            const u32x4 pr = *(const u32x4*)(smem + (((wave ^ 1) * 8 + mt) * 2 + hx) * 1024 + lane * 16);
+            const u32x4 cc = CC[b4][m][hx], ss = SS[b4][m][hx];
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float x0 = bflo(own[mt][hx][k]), x1 = bfhi(own[mt][hx][k]);
+              float y0 = bflo(pr[k]), y1 = bfhi(pr[k]);
+              if (!(wc & 1)) { y0 = -y0; y1 = -y1; }    // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin
+              o[k] = pack2bf(bfround(x0 * bflo(cc[k])) + bfround(y0 * bflo(ss[k])),
+                             bfround(x1 * bfhi(cc[k])) + bfround(y1 * bfhi(ss[k])));
+            }
+            CC[b4][m][hx] = o;
           }
         }
-        bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
-        *(u32x4*)op = o[0];
-        *(u32x4*)(op + 8) = o[1];
-      }
+      };
+      auto pin = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(CC[b4][m][0]), "+v"(CC[b4][m][1]) : : "memory");
+      };
+      auto st = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = rowof(b4 * 4 + m);
+          if (row >= Mv) continue;
+          bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
+          *(u32x4*)op = CC[b4][m][0];
+          *(u32x4*)(op + 8) = CC[b4][m][1];
+        }
+      };
+      ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); st(1);
     } else {
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
@@ -983,30 +1020,67 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
     // fused SwiGLU backward (lmod_gemm_swiglu_bwd_bf16) as its OWN instantiation: the accumulators are d(act); with the
     // saved [gate | up] pre-activations (C2) the epilogue writes [dgate | dup].  (Inside the MODE 0 epilogue this block
     // cost the plain GEMM 22 %.)  N % 16 == 0 (host-checked).
+    // Memory order: written row tile by row tile (load gate/up, compute, store) hipcc cannot lift the next loads over the
+    // previous stores (C and C2 may alias) and gfx9's one vmcnt counts loads and stores that retire out of order, so every
+    // row tile became load -> vmcnt(0) -> store -> load ...: 16 exposed round trips per tile with ONE workgroup on the CU
+    // (26 us beside a 53 us main loop at K 2048).  Here: loads of row tiles 0-3, compute, loads of 4-7, THEN the stores of
+    // 0-3, compute, stores of 4-7 — two exposed round trips.  Rows past Mv are loaded from a clamped (allocated) row and
+    // never stored.
     const int cb = col0 + wc * 64 + g * 16;
     const int Mz = min((Mv + 7) & ~7, p.M);
+    if (cb >= p.N) return;
+    bf16_t* obase = (bf16_t*)p.C + (long long)bz * p.sC + cb;
+    const bf16_t* gbase = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + cb;
+    u32x4 G[2][4][2], U[2][4][2];
+    auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+    auto ld = [&](const int b4) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int row = row0 + wr * 128 + mt * 16 + li;
-      if (cb >= p.N || row >= Mz) continue;
-      bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
-      if (row >= Mv) {           // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
+      for (int m = 0; m < 4; ++m) {
+        const bf16_t* gp = gbase + (long long)min(rowof(b4 * 4 + m), p.M - 1) * p.ldc2;
 #pragma unroll
-        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
-        continue;
+        for (int hx = 0; hx < 2; ++hx) {
+          G[b4][m][hx] = *(const u32x4*)(gp + hx * 8);
+          U[b4][m][hx] = *(const u32x4*)(gp + p.N + hx * 8);
+        }
       }
-      const bf16_t* gp = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + (long long)row * p.ldc2 + cb;
+    };
+    auto cmp = [&](const int b4) {
 #pragma unroll
-      for (int hx = 0; hx < 2; ++hx) {
-        float d8[8];
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d8[e] = acc[mt][hx * 2 + (e >> 2)][e & 3];
-        u32x4 og, ou;
-        swiglu_bwd8(d8, *(const u32x4*)(gp + hx * 8), *(const u32x4*)(gp + p.N + hx * 8), og, ou);
-        *(u32x4*)(op + hx * 8) = og;
-        *(u32x4*)(op + p.N + hx * 8) = ou;
+        for (int hx = 0; hx < 2; ++hx) {
+          float d8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d8[e] = acc[b4 * 4 + m][hx * 2 + (e >> 2)][e & 3];
+          u32x4 og, ou;
+          swiglu_bwd8(d8, G[b4][m][hx], U[b4][m][hx], og, ou);
+          G[b4][m][hx] = og;
+          U[b4][m][hx] = ou;
+        }
+    };
+    auto st = [&](const int b4) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = rowof(b4 * 4 + m);
+        if (row >= Mz) continue;
+        bf16_t* op = obase + (long long)row * p.ldc;
+        const bool z = row >= Mv;      // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          *(u32x4*)(op + hx * 8) = z ? (u32x4){0u, 0u, 0u, 0u} : G[b4][m][hx];
+          *(u32x4*)(op + p.N + hx * 8) = z ? (u32x4){0u, 0u, 0u, 0u} : U[b4][m][hx];
+        }
       }
-    }
+    };
+    // the pin ties batch 0's results to a point AHEAD of batch 1's loads: without it hipcc issues all 32 loads up front
+    // (128 registers beside the 128 accumulators -> scratch spills); with it batch 1 lands in the dead accumulators
+    auto pin = [&](const int b4) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) asm volatile("" : "+v"(G[b4][m][hx]), "+v"(U[b4][m][hx]) : : "memory");
+    };
+    ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); st(1);
     return;
   }
   if constexpr (!BK) {
@@ -1023,6 +1097,58 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   }
   char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : 2);
   const bool full = (cb + 16 <= p.N) && p.vec_ok;
+  if constexpr (MODE == 6) {
+    // C (fp32) += tile without split-K: the weight gradients of the lm_head and of the MoE experts (k_valid batches).  The
+    // generic loop below compiles to load -> vmcnt(0) -> add -> store per 16 bytes (the next load cannot be lifted over a
+    // store that may alias): 32 exposed round trips per tile with one workgroup on the CU.  Here, as in the MODE 4 epilogue:
+    // old values of row tiles 0-3, add, old values of 4-7, THEN the stores of 0-3, add, stores of 4-7.
+    if (p.out_f32 && p.accumulate && p.splitk <= 1 && full && !p.act) {
+      float* Cf = (float*)Cb;
+      auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+      f32x4 R[2][4][4];
+      auto ld = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float* cp = Cf + (long long)min(rowof(b4 * 4 + m), p.M - 1) * p.ldc + cb;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) R[b4][m][x] = *(const f32x4*)(cp + 4 * x);
+        }
+      };
+      auto add = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float v[16];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[b4 * 4 + m][nt][q] + bia[nt * 4 + q];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            f32x4 o = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+            o += R[b4][m][x];
+            R[b4][m][x] = o;
+          }
+        }
+      };
+      auto pin = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          asm volatile("" : "+v"(R[b4][m][0]), "+v"(R[b4][m][1]), "+v"(R[b4][m][2]), "+v"(R[b4][m][3]) : : "memory");
+      };
+      auto st = [&](const int b4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = rowof(b4 * 4 + m);
+          if (row >= Mv) continue;
+          float* cp = Cf + (long long)row * p.ldc + cb;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) *(f32x4*)(cp + 4 * x) = R[b4][m][x];
+        }
+      };
+      ld(0); add(0); pin(0); ld(1); st(0); add(1); st(1);
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int row = row0 + wr * 128 + mt * 16 + li;
@@ -1541,7 +1667,7 @@ static void allow_lds(KT kern, int bytes, bool& done) {      // once per kernel 
 }
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
-  static bool a4 = false, a8 = false, a84 = false;
+  static bool a4 = false, a8 = false, a84 = false, a86 = false;
   const int w = gemm_waves();
   if (w == 4) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
@@ -1549,6 +1675,9 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
     allow_lds(gemm_256_kernel<4>, 8 * G256_SLOT, a84);
     hipLaunchKernelGGL(gemm_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  } else if (MODE == 0 && p.out_f32 && p.accumulate && p.splitk <= 1 && p.vec_ok) {   // fp32 read-modify-write: see MODE 6
+    allow_lds(gemm_256_kernel<6>, 8 * G256_SLOT, a86);
+    hipLaunchKernelGGL(gemm_256_kernel<6>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   } else {
     allow_lds(gemm_256_kernel<MODE>, 8 * G256_SLOT, a8);
     hipLaunchKernelGGL(gemm_256_kernel<MODE>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
