@@ -42,15 +42,22 @@ struct GemmP {
 
 // Fused SwiGLU epilogue (gemm_swiglu_256): v[0..7] are 8 gate pre-activations, v[8..15] the matching 8 up values.
 // Same roundings as GEMM + the separate kernel: bf16 gate/up, bf16 silu, bf16 product (qwen2/modeling_qwen2.py:186-187).
-__device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
+// bf16 roundings go through v_cvt_pk_bf16_f32 on PAIRS (one convert + two unpacks per pair; rounding one value at a time was
+// a convert + a shift each): gp / up are the packed bf16 pre-activations, the very words a training forward also stores.
+__device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16], u32x4& gp, u32x4& up) {
   u32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float g0 = bfround(v[2 * k]), g1 = bfround(v[2 * k + 1]);
-    const float s0 = bfround(fast_silu(g0)), s1 = bfround(fast_silu(g1));
-    o[k] = pack2bf(s0 * bfround(v[8 + 2 * k]), s1 * bfround(v[8 + 2 * k + 1]));
+    gp[k] = pack2bf(v[2 * k], v[2 * k + 1]);
+    up[k] = pack2bf(v[8 + 2 * k], v[8 + 2 * k + 1]);
+    const uint32_t sw = pack2bf(fast_silu(bflo(gp[k])), fast_silu(bfhi(gp[k])));
+    o[k] = pack2bf(bflo(sw) * bflo(up[k]), bfhi(sw) * bfhi(up[k]));
   }
   return o;
+}
+__device__ __forceinline__ u32x4 swiglu_pairs(const float (&v)[16]) {
+  u32x4 gp, up;
+  return swiglu_pairs(v, gp, up);
 }
 
 // SwiGLU backward on 8 (dact, gate, up) triples packed as bf16 pairs — the arithmetic of swiglu_bwd_kernel (rowops.hip).
@@ -58,10 +65,12 @@ __device__ __forceinline__ void swiglu_bwd8(const float (&d)[8], const u32x4 g, 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float gg[2] = {bflo(g[k]), bfhi(g[k])}, uu[2] = {bflo(u[k]), bfhi(u[k])};
+    const uint32_t dw = pack2bf(d[2 * k], d[2 * k + 1]);      // the standalone path rounds dact to bf16 in HBM
+    const float dd2[2] = {bflo(dw), bfhi(dw)};
     float rg[2], ru[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float dd = bfround(d[2 * k + e]);                 // the standalone path rounds dact to bf16 in HBM
+      const float dd = dd2[e];
       const float sg = fast_sigmoid(gg[e]);
       rg[e] = dd * uu[e] * (sg * (1.f + gg[e] * (1.f - sg)));
       ru[e] = dd * (gg[e] * sg);
@@ -872,10 +881,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q];
-      *(u32x4*)(Cact + (long long)row * p.ldc + cs) = swiglu_pairs(v);
+      u32x4 o0, o1;                   // packed bf16 [gate], [up]: what the activation is computed from AND what training keeps
+      *(u32x4*)(Cact + (long long)row * p.ldc + cs) = swiglu_pairs(v, o0, o1);
       if (Cgu) {
-        const u32x4 o0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        const u32x4 o1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
         *(u32x4*)(Cgu + (long long)row * p.ldc2 + cs) = o0;
         *(u32x4*)(Cgu + (long long)row * p.ldc2 + p.N + cs) = o1;
       }
@@ -1062,14 +1070,24 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int row = rowof(b4 * 4 + m);
-        if (row >= Mz) continue;
+        if (row >= Mv) continue;
         bf16_t* op = obase + (long long)row * p.ldc;
-        const bool z = row >= Mv;      // rows up to the next multiple of 8 are zeroed: a k_valid wgrad reads whole 8-row chunks
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
-          *(u32x4*)(op + hx * 8) = z ? (u32x4){0u, 0u, 0u, 0u} : G[b4][m][hx];
-          *(u32x4*)(op + p.N + hx * 8) = z ? (u32x4){0u, 0u, 0u, 0u} : U[b4][m][hx];
+          *(u32x4*)(op + hx * 8) = G[b4][m][hx];
+          *(u32x4*)(op + p.N + hx * 8) = U[b4][m][hx];
         }
+      }
+    };
+    auto zero_tail = [&]() {           // rows Mv .. roundup8(Mv)-1 are zeroed: a k_valid wgrad reads whole 8-row chunks
+      if (Mz == Mv) return;            // (its own pass: merged into st() hipcc turned the branch into one select per output register)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = rowof(mt);
+        if (row < Mv || row >= Mz) continue;
+        bf16_t* op = obase + (long long)row * p.ldc;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
       }
     };
     // the pin ties batch 0's results to a point AHEAD of batch 1's loads: without it hipcc issues all 32 loads up front
@@ -1081,6 +1099,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         for (int hx = 0; hx < 2; ++hx) asm volatile("" : "+v"(G[b4][m][hx]), "+v"(U[b4][m][hx]) : : "memory");
     };
     ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); st(1);
+    zero_tail();
     return;
   }
   if constexpr (!BK) {

@@ -16,7 +16,8 @@ args = ap.parse_args()
 P, I, Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 SIG = {"lmod_gemm_bf16_nt": [P, P, P, P, I, I, I, I, I, I, I, Q, Q, Q, P, P, I, I, I, P],
        "lmod_gemm_qkv_rope_bf16": [P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
-       "lmod_gemm_swiglu_bwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I, Q, Q, Q, Q, P, P]}
+       "lmod_gemm_swiglu_bwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I, Q, Q, Q, Q, P, P],
+       "lmod_gemm_swiglu_bf16": [P, P, P, P, I, I, I, I, I, I, I, I, Q, Q, Q, Q, P, P]}
 libs = {"new": ctypes.CDLL(os.path.join(ROOT, "llava-mod_amd", "llavamod", "_lib", "liblmod_hip.so")), "old": ctypes.CDLL(args.other)}
 for lib in libs.values():
     for n, a in SIG.items():
@@ -46,6 +47,18 @@ def case_swiglu_bwd(M, N, K, tag):
     return tag, 2.0 * M * N * K, run, outs
 
 
+def case_swiglu_fwd(M, N, K, tag, keep):
+    A, W = rnd(M, K), rnd(2 * N, K)
+    outs = {k: torch.empty(M, N + (2 * N if keep else 0), device=dev, dtype=bf) for k in libs}      # [act | gate | up]
+    def run(k):
+        act = outs[k][:, :N]
+        gu = outs[k][:, N:] if keep else None
+        rc = libs[k].lmod_gemm_swiglu_bf16(ptr(A), ptr(W), ptr(act), ptr(gu), M, N, K, K, K, outs[k].stride(0), outs[k].stride(0),
+                                           1, 0, 0, 0, 0, None, None)
+        assert rc == 0, rc
+    return tag, 4.0 * M * N * K, run, outs
+
+
 def case_qkv_rope(M, N, K, tag, S=2048):
     A, W, bias = rnd(M, K), rnd(N, K), rnd(N)
     cos, sin = rnd(S, 128), rnd(S, 128)
@@ -70,7 +83,9 @@ def case_acc(M, N, K, tag, batch=1, kv=None):
     return tag, fl, run, outs
 
 
-cases = [lambda: case_swiglu_bwd(32768, 5504, 2048, "swiglu_bwd student dense [32768 x 5504 x 2048]"),
+cases = [lambda: case_swiglu_fwd(32768, 11008, 4096, "swiglu fwd teacher (act only) [32768 x 2*11008 x 4096]", False),
+         lambda: case_swiglu_fwd(32768, 5504, 2048, "swiglu fwd student (act + [gate|up]) [32768 x 2*5504 x 2048]", True),
+         lambda: case_swiglu_bwd(32768, 5504, 2048, "swiglu_bwd student dense [32768 x 5504 x 2048]"),
          lambda: case_swiglu_bwd(16384, 5504, 2048, "swiglu_bwd [16384 x 5504 x 2048]"),
          lambda: case_qkv_rope(32768, 6144, 2048, "qkv_rope student [32768 x 6144 x 2048]"),
          lambda: case_qkv_rope(32768, 12288, 4096, "qkv_rope teacher [32768 x 12288 x 4096]"),
