@@ -29,6 +29,19 @@
 #include <type_traits>
 
 #define F2_TB 16384
+#ifndef F2_TRACE
+#define F2_TRACE 0                 // debug build (tools/attn_trace.py): s_memtime stamps of ONE workgroup's life into f2_trace_buf
+#endif
+#if F2_TRACE
+#ifndef F2_TRACE_Y
+#define F2_TRACE_Y 1
+#endif
+__device__ unsigned long long f2_trace_buf[8 * 128];
+#define F2_STAMP(k) do { if (trace_on && (threadIdx.x & 63) == 0) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); f2_trace_buf[(threadIdx.x >> 6) * 128 + (k)] = t_; } } while (0)
+#else
+#define F2_STAMP(k) do { } while (0)
+#endif
 #ifndef F2_THR
 #define F2_THR 6.0f
 #endif
@@ -37,6 +50,9 @@
 #endif
 #ifndef F2_SCHED
 #define F2_SCHED 1
+#endif
+#ifndef F2_TOUCH
+#define F2_TOUCH 0                  // > 0: L2 touch of the K / V tiles this many iterations ahead of their register loads
 #endif
 
 // The statements between two MFMAs are ordinary (movable) code: pinning one result of each slice with an empty volatile asm
@@ -252,8 +268,9 @@ __device__ __forceinline__ float half_swap_sum(float v) {
 }
 
 template <bool CAUSAL>
-__device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, int h, int b) {
+__device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, int h, int b, const int tbase = 0, const bool trace_on = false) {
   constexpr int QB = 256;
+  F2_STAMP(tbase + 0);
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));     // per-lane addresses are re-derived per pass, not hoisted (and spilled) across passes
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -298,6 +315,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + 128) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + 128) * 2), 0x00020000);
   u32x4 kr0, kr1, vr0, vr1;
+#if F2_TOUCH
+  uint32_t tk0 = 0, tv0 = 0;
+#endif
   auto gload_k = [&](int t) {
     const uint32_t adv = (uint32_t)(t * 64 * p.ldk) * 2u;
     kr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, kgo + adv, 0, 0));
@@ -467,6 +487,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     gload_v(0);
   }
   __syncthreads();
+  F2_STAMP(tbase + 1);
 
   // Staging (one register set per tensor): the registers hold K(j+1) and V(j), loaded during iteration j-1.  They are written
   // to LDS right AFTER the barrier that ended iteration j-1 (their buffers' last readers are done) and the loads of K(j+2),
@@ -476,8 +497,22 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     if (F2_ABL != 5) {
       if (j + 1 < ntiles) write_k((j + 1) & 1);
       if (j < ntiles) write_v(j & 1);
+#if F2_TOUCH
+      asm volatile("" :: "v"(tk0), "v"(tv0));   // last iteration's touches: older than anything in flight now
+#endif
       if (j + 2 < ntiles) gload_k(j + 2);
       if (j + 1 < ntiles) gload_v(j + 1);
+#if F2_TOUCH
+      // L2 touch: one dword per 32 bytes of the tiles whose register loads are issued F2_TOUCH iterations from now (thread -> row
+      // tid >> 3, byte (tid & 7) * 32; tiles past the end are out of the descriptor's range: no traffic).  The register loads have
+      // ONE iteration (~4.9k cycles) to land, which is the loaded HBM latency: the first workgroup pass over a (batch, head)'s
+      // K / V ran at 49 hundred-cycles per tile, a pass over L2-hot tiles at 44.8 (tools/attn_trace.py).
+      {
+        const uint32_t tr = (uint32_t)(tid >> 3), tc = (uint32_t)(tid & 7) * 32u;
+        tk0 = __builtin_amdgcn_raw_buffer_load_b32(rk, (((uint32_t)(j + 2 + F2_TOUCH) * 64u + tr) * (uint32_t)p.ldk) * 2u + tc, 0, 0);
+        tv0 = __builtin_amdgcn_raw_buffer_load_b32(rv, (((uint32_t)(j + 1 + F2_TOUCH) * 64u + tr) * (uint32_t)p.ldv) * 2u + tc, 0, 0);
+      }
+#endif
     }
     const bool do_a = (j < ntw), do_pv = (j >= 1 && j <= ntw);
     // masked when the key's position inside the tile exceeds mthr (covers the causal diagonal and the key length)
@@ -508,7 +543,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (F2_ABL != 1) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    F2_STAMP(tbase + 2 + j);
   }
+  F2_STAMP(tbase + 57);
 
   // ---- epilogue: lane (query l31, half hi) holds features dt*32 + hi*16 + r of its query
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // last asm MFMA -> accumulator reads
@@ -535,6 +572,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
       p.LSE[((long long)b * p.nh + h) * p.S + q] =
           (lt > 0.f) ? mrun * p.scale + __builtin_amdgcn_logf(lt) * 0.6931471805599453f : -INFINITY;
   }
+  F2_STAMP(tbase + 58);
 }
 
 // Causal work per query block grows linearly with its index: every workgroup takes the pair (nqb-1-x, x), so all
@@ -550,8 +588,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
     const int npass = (2 * x + 1 < nqb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
+#if F2_TRACE
+      const bool trace_on = blockIdx.x == 3 && blockIdx.y == F2_TRACE_Y && blockIdx.z == 5;
+      fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z, pass * 60, trace_on);
+      __syncthreads();
+      F2_STAMP(pass * 60 + 59);
+#else
       fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z);
       __syncthreads();
+#endif
     }
   } else {
     fwd2_block<false>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
@@ -571,3 +616,9 @@ void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream) {
   if (causal) hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(512), lds, stream, p);
   else hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(512), lds, stream, p);
 }
+
+#if F2_TRACE
+extern "C" int lmod_debug_attn_trace(void* host_dst) {      // trace builds only (not part of the C-ABI)
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(f2_trace_buf), sizeof(unsigned long long) * 8 * 128);
+}
+#endif
