@@ -547,4 +547,7 @@ def init_distributed():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=opts)
     else:
         dist.init_process_group("gloo")
+        if torch.cuda.is_available():          # functional runs with more ranks than GPUs (ranks share devices, exchange through gloo)
+            local %= torch.cuda.device_count()
+            torch.cuda.set_device(local)
     return rank, local, world

@@ -178,18 +178,21 @@ def _cpu_kernels():
     K.adamw_step, K.sumsq, K.clip_coef, K.cast_f32_bf16 = adamw_step, sumsq, clip_coef, cast_f32_bf16
 
 
-def _zero2_worker(rank, world, port, q):
+def _zero2_worker(rank, world, port, q, device="cpu"):
+    """device "cpu": the four HIP kernels are replaced by torch stand-ins (this file's tests).  device "cuda": the REAL kernels, both
+    ranks on the one GPU of the box, collectives through gloo (tests/test_two_ranks_one_gpu.py)."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")      # CPU test even on a box that has a GPU
     from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
     from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2DecoderLayer, init_normal_
     from llavamod.model.moe_layer import MoE
-    _cpu_kernels()
+    if device == "cpu":
+        _cpu_kernels()
     init_distributed()
 
     def build():
         cfg = Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1)
-        layer = Qwen2DecoderLayer(cfg, "cpu")
+        layer = Qwen2DecoderLayer(cfg, device)
         layer.mlp = MoE(64, layer.mlp, num_experts=4, k=2, capacity_factor=1.5, min_capacity=0)
         init_normal_(layer, 0.02, 0)
         for n, p in layer.named_parameters():                 # experts + router + a BIASED fused weight (q/k/v)
@@ -197,7 +200,7 @@ def _zero2_worker(rank, world, port, q):
         return layer
 
     def fake_grads(gb, step):                                  # rank-dependent, deterministic, O(1) magnitude
-        i = torch.arange(gb.numel, dtype=torch.float32)
+        i = torch.arange(gb.numel, dtype=torch.float32, device=gb.flat.device)
         gb.flat.copy_(torch.sin(i * 0.37 + step) * (0.5 + rank) + 0.1 * rank)
 
     def run(zero2, grad_dtype=torch.float32, clip=1.0, use_hooks=True):
@@ -227,7 +230,7 @@ def _zero2_worker(rank, world, port, q):
     q2 = ref_layer.self_attn._qkv
     q2.note_use(); q2.grad_done()
     d2.finish()
-    other = torch.sin(torch.arange(ref_gb.numel, dtype=torch.float32) * 0.37 + 7) * (0.5 + (1 - rank)) + 0.1 * (1 - rank)
+    other = torch.sin(torch.arange(ref_gb.numel, dtype=torch.float32, device=ref_gb.flat.device) * 0.37 + 7) * (0.5 + (1 - rank)) + 0.1 * (1 - rank)
     assert torch.allclose(ref_gb.flat, mine + other, atol=1e-6), "a span was not summed over the ranks"
 
     z_layer, z_gb, z_opt, z_norms = run(True)
@@ -312,17 +315,17 @@ def _zero2_worker(rank, world, port, q):
     q.put((rank, "ok"))
 
 
-def _spawn(target):
+def _spawn(target, *extra, timeout=180):
     import tempfile
     os.environ["LMOD_TEST_TMP"] = tempfile.mkdtemp(prefix="lmod_gloo_")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + tuple(extra)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(timeout)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, "ok"), (1, "ok")]
