@@ -39,6 +39,16 @@ struct GemmP {
 };
 
 #define GEMM_OOB 0x80000000u
+#ifndef G256_NT_C
+#define G256_NT_C 0                // 1: the 256-tile kernels store their output tiles non-temporally (streamed past the L2's LRU)
+#endif
+__device__ __forceinline__ void st_c(void* p, const u32x4 v) {
+#if G256_NT_C
+  __builtin_nontemporal_store(v, (u32x4*)p);
+#else
+  *(u32x4*)p = v;
+#endif
+}
 
 // Fused SwiGLU epilogue (gemm_swiglu_256): v[0..7] are 8 gate pre-activations, v[8..15] the matching 8 up values.
 // Same roundings as GEMM + the separate kernel: bf16 gate/up, bf16 silu, bf16 product (qwen2/modeling_qwen2.py:186-187).
@@ -882,10 +892,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][nt][q];
       u32x4 o0, o1;                   // packed bf16 [gate], [up]: what the activation is computed from AND what training keeps
-      *(u32x4*)(Cact + (long long)row * p.ldc + cs) = swiglu_pairs(v, o0, o1);
+      st_c(Cact + (long long)row * p.ldc + cs, swiglu_pairs(v, o0, o1));
       if (Cgu) {
-        *(u32x4*)(Cgu + (long long)row * p.ldc2 + cs) = o0;
-        *(u32x4*)(Cgu + (long long)row * p.ldc2 + p.N + cs) = o1;
+        st_c(Cgu + (long long)row * p.ldc2 + cs, o0);
+        st_c(Cgu + (long long)row * p.ldc2 + p.N + cs, o1);
       }
     }
     return;
@@ -1007,8 +1017,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
           const int row = rowof(b4 * 4 + m);
           if (row >= Mv) continue;
           bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
-          *(u32x4*)op = CC[b4][m][0];
-          *(u32x4*)(op + 8) = CC[b4][m][1];
+          st_c(op, CC[b4][m][0]);
+          st_c(op + 8, CC[b4][m][1]);
         }
       };
       ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); st(1);
@@ -1018,8 +1028,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         const int row = row0 + wr * 128 + mt * 16 + li;
         if (row >= Mv || cb >= p.N) continue;
         bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
-        *(u32x4*)op = own[mt][0];
-        *(u32x4*)(op + 8) = own[mt][1];
+        st_c(op, own[mt][0]);
+        st_c(op + 8, own[mt][1]);
       }
     }
     return;
@@ -1074,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         bf16_t* op = obase + (long long)row * p.ldc;
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
-          *(u32x4*)(op + hx * 8) = G[b4][m][hx];
+          *(u32x4*)(op + hx * 8) = G[b4][m][hx];          // (not st_c: non-temporal stores cost this epilogue 3.5-7 %)
           *(u32x4*)(op + p.N + hx * 8) = U[b4][m][hx];
         }
       }
@@ -1206,8 +1216,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
       if (full && !p.accumulate) {
         u32x4 o0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         u32x4 o1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
-        *(u32x4*)(cp) = o0;
-        *(u32x4*)(cp + 8) = o1;
+        st_c(cp, o0);
+        st_c(cp + 8, o1);
       } else {
 #pragma unroll
         for (int x = 0; x < 16; ++x)
@@ -1364,6 +1374,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int abase = (wr * 128 + li) * 128, bbase = 32768 + (wc * 128 + li) * 128;
   const int ph[2] = {((g) ^ (li & 7)) * 16, ((4 + g) ^ (li & 7)) * 16};
   bf16x8 fa[2][8], fb[2][8];
+#ifndef G4_DEEP
+#define G4_DEEP 1
+#endif
+#ifndef G4_ABL
+#define G4_ABL 0                    // timing ablations of the deep schedule (WRONG RESULTS): 1 no barriers, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no vmcnt wait, 16 every LDS-DMA out of range (no traffic)
+#endif
 #define G4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
   auto stage_piece = [&](int t, int j) {                   // tiles past the end are fully out of bounds: zero fill, no traffic
     const int k0 = t * 64;
@@ -1372,6 +1388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
   };
+#if !G4_DEEP
   // one k-step: 64 MFMAs on (fa[cur], fb[cur]); in their shadow the fragments of the next k-step (stage ts, k-half kn) are
   // read into (fa[cur^1], fb[cur^1]) and, if DMA, the 16 LDS-DMA pieces of tile td are issued
   auto kstep = [&](const int cur, const int ts, const int kn, const bool dma, const int td) {
@@ -1418,6 +1435,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kstep(1, t + 1, 0, true, t + 2);                       // k-step 1; reads tile t+1's k-step-0 operands, stages tile t+2
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+  // Schedule (G4_DEEP, the default): what hipBLASLt's hand-written gfx950 kernel of the same shape does (4 waves, 128x128 per
+  // wave, 256x256x64 tile; its main loop read from the library's code object with llvm-objdump — 1587 TF on the teacher QKV
+  // shape against 1270 TF for this kernel's previous one-barrier schedule, which waited vmcnt(0) at mid tile: 0.5-0.75 tiles of
+  // cover for the LDS-DMA).  Per K tile t (stage X = t & 1 holds it, stage Y holds t + 1, k-step-0 fragments are in registers):
+  //   k-step 0, MFMAs 0-15: the A fragments of k-step 1 are read; at MFMA 36 every wave has them: barrier 1 frees X's A half
+  //             MFMAs 37-52: LDS-DMA of A(t+2) into X, interleaved with the reads of the B fragments of k-step 1
+  //             end: those reads have landed: barrier 2 frees X's B half
+  //   k-step 1, MFMAs 1-15: LDS-DMA of B(t+2) into X
+  //             MFMA 28: vmcnt(16) — everything issued before this tile's 16 pieces, i.e. all of tile t+1 — barrier 3
+  //             MFMAs 29-59: the k-step-0 fragments of tile t+1 are read from Y
+  // A piece has 1.0-1.4 tiles to land instead of 0.5-0.75, for two more barriers per tile.
+  auto dma_a = [&](const int td, const int j) {
+    const int k0 = td * 64;
+    char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
+    const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
+  };
+  auto dma_b = [&](const int td, const int j) {
+    const int k0 = td * 64;
+    char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
+    const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
+  };
+#define G4_MFMA(cur, idx) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(idx) >> 3][(idx) & 7]) : "v"(fb[cur][(idx) & 7]), "v"(fa[cur][(idx) >> 3]))
+#define G4_SB() __builtin_amdgcn_sched_barrier(0)
+
+#pragma unroll
+  for (int j = 0; j < 8; ++j) stage_piece(0, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) stage_piece(1, j);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // tile 0 landed (tile 1's 16 pieces may still fly)
+  G4_BARRIER();
+  {
+    const char* s = smem + ph[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * 2048); fb[0][i] = *(const bf16x8*)(s + bbase + i * 2048); }
+  }
+  for (int t = 0; t < nkt; ++t) {
+    const char* sx = smem + (t & 1) * G4_STAGE + ph[1];              // this tile, k-half 1
+    const char* sy = smem + ((t + 1) & 1) * G4_STAGE + ph[0];        // next tile, k-half 0
+#pragma unroll
+    for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 0
+      G4_MFMA(0, idx);
+      // A fragments of k-step 1: behind MFMAs 0, 2, ..., 14
+      if (!(G4_ABL & 4) && idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * 2048); G4_SB(); }
+      if (idx == 21) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 1
+      // A(t+2): behind MFMAs 22, 25, ..., 43;  B fragments of k-step 1: behind 24, 27, ..., 45
+      if (!(G4_ABL & 2) && idx >= 22 && idx <= 43 && (idx - 22) % 3 == 0) { dma_a(t + 2, (idx - 22) / 3); G4_SB(); }
+      if (!(G4_ABL & 4) && idx >= 24 && idx <= 45 && (idx - 24) % 3 == 0) { fb[1][(idx - 24) / 3] = *(const bf16x8*)(sx + bbase + ((idx - 24) / 3) * 2048); G4_SB(); }
+      if (idx == 54) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 2
+      if (!(G4_ABL & 2) && idx >= 55 && idx <= 61 && (idx - 55) % 3 == 0) { dma_b(t + 2, (idx - 55) / 3); G4_SB(); }       // B(t+2) pieces 0-2
+    }
+    G4_SB();
+#pragma unroll
+    for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 1
+      G4_MFMA(1, idx);
+      if (!(G4_ABL & 2) && idx <= 12 && idx % 3 == 0) { dma_b(t + 2, 3 + idx / 3); G4_SB(); }                               // pieces 3-7
+      if (idx == 22) { if (!(G4_ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 3
+      // k-step-0 fragments of tile t+1: two behind every three MFMAs, the last one 12 MFMAs ahead of the loop end
+      if (!(G4_ABL & 4) && idx >= 23 && idx <= 46 && (idx - 23) % 3 != 2) {
+        const int f = ((idx - 23) / 3) * 2 + (idx - 23) % 3;         // 0..15: A fragments 0-7, then B fragments 0-7
+        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * 2048);
+        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * 2048);
+        G4_SB();
+      }
+    }
+    G4_SB();
+  }
+#undef G4_MFMA
+#undef G4_SB
+#endif
   // the asm MFMAs are invisible to the hazard recognizer: let the last accumulator writes retire before reading them
   asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
 #undef G4_BARRIER
