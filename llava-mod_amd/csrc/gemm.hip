@@ -1447,17 +1447,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //             MFMA 28: vmcnt(16) — everything issued before this tile's 16 pieces, i.e. all of tile t+1 — barrier 3
   //             MFMAs 29-59: the k-step-0 fragments of tile t+1 are read from Y
   // A piece has 1.0-1.4 tiles to land instead of 0.5-0.75, for two more barriers per tile.
-  auto dma_a = [&](const int td, const int j) {
+  // K64 (the reduction length is a multiple of 64: every shape of the step but the MoE experts' routed-row counts): a tile is wholly
+  // live or wholly past the end, so "past the end" is a SCALAR choice of descriptor (zero records: every lane out of range, no
+  // traffic) instead of one v_cndmask per LDS-DMA in the MFMA gaps.
+  const __amdgpu_buffer_rsrc_t rsAz = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsBz = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0, 0x00020000);
+  auto dma_a = [&](auto k64_t, const int td, const int j) {
     const int k0 = td * 64;
     char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
-    const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
+    if constexpr (decltype(k64_t)::value) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsAz : rsA, LDS_PTR(dst + j * 4096), 16, voA[j], k0 * 2, 0, 0);
+    } else {
+      const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
+    }
   };
-  auto dma_b = [&](const int td, const int j) {
+  auto dma_b = [&](auto k64_t, const int td, const int j) {
     const int k0 = td * 64;
     char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
-    const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
+    if constexpr (decltype(k64_t)::value) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsBz : rsB, LDS_PTR(dst + 32768 + j * 4096), 16, voB[j], k0 * 2, 0, 0);
+    } else {
+      const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
+    }
   };
 #define G4_MFMA(cur, idx) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(idx) >> 3][(idx) & 7]) : "v"(fb[cur][(idx) & 7]), "v"(fa[cur][(idx) >> 3]))
 #define G4_SB() __builtin_amdgcn_sched_barrier(0)
@@ -1473,6 +1486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * 2048); fb[0][i] = *(const bf16x8*)(s + bbase + i * 2048); }
   }
+  auto run_loop = [&](auto k64_t) {
   for (int t = 0; t < nkt; ++t) {
     const char* sx = smem + (t & 1) * G4_STAGE + ph[1];              // this tile, k-half 1
     const char* sy = smem + ((t + 1) & 1) * G4_STAGE + ph[0];        // next tile, k-half 0
@@ -1482,18 +1496,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // A fragments of k-step 1: behind MFMAs 0, 2, ..., 14
       if (!(G4_ABL & 4) && idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * 2048); G4_SB(); }
       if (idx == 21) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 1
-      // A(t+2): behind MFMAs 22, 25, ..., 43;  B fragments of k-step 1: behind 24, 27, ..., 45
-      if (!(G4_ABL & 2) && idx >= 22 && idx <= 43 && (idx - 22) % 3 == 0) { dma_a(t + 2, (idx - 22) / 3); G4_SB(); }
+      // A(t+2): behind MFMAs 22, 27, ..., 57 (the four waves share ONE address unit, 16 cycles per 1 KiB piece: pieces issued every 3
+      // MFMAs by all four waves oversubscribe it and the in-order waves stall behind their own VMEM issue);  B fragments of k-step 1:
+      // behind 24, 27, ..., 45
+      if (!(G4_ABL & 2) && idx >= 22 && idx <= 57 && (idx - 22) % 5 == 0) { dma_a(k64_t, t + 2, (idx - 22) / 5); G4_SB(); }
       if (!(G4_ABL & 4) && idx >= 24 && idx <= 45 && (idx - 24) % 3 == 0) { fb[1][(idx - 24) / 3] = *(const bf16x8*)(sx + bbase + ((idx - 24) / 3) * 2048); G4_SB(); }
       if (idx == 54) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 2
-      if (!(G4_ABL & 2) && idx >= 55 && idx <= 61 && (idx - 55) % 3 == 0) { dma_b(t + 2, (idx - 55) / 3); G4_SB(); }       // B(t+2) pieces 0-2
+      if (!(G4_ABL & 2) && idx == 62) { dma_b(k64_t, t + 2, 0); G4_SB(); }                                                       // B(t+2) piece 0
     }
     G4_SB();
 #pragma unroll
     for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 1
       G4_MFMA(1, idx);
-      if (!(G4_ABL & 2) && idx <= 12 && idx % 3 == 0) { dma_b(t + 2, 3 + idx / 3); G4_SB(); }                               // pieces 3-7
-      if (idx == 22) { if (!(G4_ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 3
+      if (!(G4_ABL & 2) && (idx == 5 || idx == 13)) { dma_b(k64_t, t + 2, idx == 5 ? 1 : 2); G4_SB(); }                          // pieces 1, 2
+      // barrier 3: everything older than this tile's 11 pieces so far (A 0-7, B 0-2) has landed, i.e. all of tile t+1
+      if (idx == 22) { if (!(G4_ABL & 8)) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }
+      // B(t+2) pieces 3-7 in the free slots of the fragment reads below, the last one 11 MFMAs ahead of the loop end
+      if (!(G4_ABL & 2) && (idx == 25 || idx == 31 || idx == 37 || idx == 43 || idx == 52)) { dma_b(k64_t, t + 2, idx == 52 ? 7 : 3 + (idx - 25) / 6); G4_SB(); }
       // k-step-0 fragments of tile t+1: two behind every three MFMAs, the last one 12 MFMAs ahead of the loop end
       if (!(G4_ABL & 4) && idx >= 23 && idx <= 46 && (idx - 23) % 3 != 2) {
         const int f = ((idx - 23) / 3) * 2 + (idx - 23) % 3;         // 0..15: A fragments 0-7, then B fragments 0-7
@@ -1504,6 +1523,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     G4_SB();
   }
+  };
+  if ((Kv & 63) == 0) run_loop(std::true_type{}); else run_loop(std::false_type{});
 #undef G4_MFMA
 #undef G4_SB
 #endif

@@ -30,13 +30,17 @@ class Sampler(threading.Thread):
             self.rows.append(row); time.sleep(0.01)
 
 
-M, N, Kd = 32768, 12288, 4096
+M, N, Kd = [int(v) for v in os.environ.get("SHAPE", "32768,12288,4096").split(",")]
+FUSED = os.environ.get("FUSED") == "1"            # compare on the fused [gate; up] weight: vendor plain GEMM vs our fused SwiGLU GEMM (same flops)
+if FUSED and "SHAPE" not in os.environ:
+    N = 22016
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 rnd = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
 x, w = rnd(M, Kd), rnd(N, Kd)
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 cards = sensors()
-arms = [("vendor F.linear", lambda: F.linear(x, w)), ("ours 8-wave", lambda: K.gemm_nt(x, w, out=out))]
+ours = (lambda: K.gemm_swiglu(x, w)) if FUSED else (lambda: K.gemm_nt(x, w, out=out))
+arms = [("vendor F.linear", lambda: F.linear(x, w)), ("ours " + os.environ.get("LMOD_GEMM_WAVES", "8") + "-wave" + (" fused SwiGLU" if FUSED else ""), ours)]
 with torch.no_grad():
     for rnd_ in range(2):
         for name, f in arms:
