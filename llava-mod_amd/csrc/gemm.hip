@@ -411,7 +411,10 @@ extern "C" int lmod_debug_gemm_trace(uint32_t* host_out) {
 // swaps those images between wave columns 2c <-> 2c+1 through the (now idle) 128 KiB of LDS, and applies
 // q*cos + rotate_half(q)*sin with the roundings of rope_kernel (rowops.hip) — bit-identical to GEMM + lmod_rope, one pass
 // over the QKV buffer less.  Tiles at or past rope_cols (the V heads) are stored as they are.
-template <int MODE>
+// K64: the host knows that every reduction length this launch sees is a multiple of 64 (K % 64 == 0, no k_valid): a K tile is wholly
+// live or wholly past the end, so "past the end" is a SCALAR choice of descriptor (zero records: no traffic) instead of one
+// v_cndmask per LDS-DMA in the MFMA gaps (the 4-wave kernel gained 2 % from the same change).
+template <int MODE, bool K64 = false>
 __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
   constexpr bool AK = (MODE == 2), BK = (MODE == 2 || MODE == 3);      // operand stored reduction-major?
@@ -486,6 +489,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
   const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE == 1 ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsAz = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0, 0x00020000);      // K64: tiles past the end
+  const __amdgpu_buffer_rsrc_t rsBz = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0, 0x00020000);
 
   // ---- staging offsets: this wave fills half-tile rows 16*wave + 8*j + (lane>>3), physical chunk lane&7 ----
   const int cchunk = (lane & 7) ^ (lane >> 3);
@@ -545,6 +550,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
         uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
         if (k0 + wave * 8 + j * 4 + (lane >> 4) >= Kv) v = GEMM_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + j * 1024), 16, v, 0, 0, G256_DMA_AUX);
+      }
+    } else if constexpr (K64) {
+      const bool past = (k0 >= Kv);                         // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j < jlo || j >= jhi) continue;
+        const uint32_t v = (kind < 2) ? voA[kind & 1][j] : voB[kind & 1][j];
+        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(past ? rsAz : rsA, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, G256_DMA_AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(past ? rsBz : rsB, LDS_PTR(dst + j * 1024), 16, v, k0 * 2, 0, G256_DMA_AUX);
       }
     } else {
       const bool dead = (k0 + cchunk * 8 >= Kv);
@@ -1794,6 +1808,19 @@ template <typename KT>
 static void allow_lds(KT kern, int bytes, bool& done) {      // once per kernel instance, not once per launch
   if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done = true; }
 }
+// one launch of the 8-wave kernel: the K64 instantiation when every reduction length of the launch is a multiple of 64
+static inline bool k64_ok(const GemmP& p) { return (p.K & 63) == 0 && !p.k_valid; }      // (split-K chunks are multiples of 64)
+template <int MODE>
+static void launch_256x(const GemmP& p, long long nwg, hipStream_t stream) {
+  static bool a0 = false, a1 = false;
+  if (k64_ok(p)) {
+    allow_lds(gemm_256_kernel<MODE, true>, 8 * G256_SLOT, a1);
+    hipLaunchKernelGGL((gemm_256_kernel<MODE, true>), dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  } else {
+    allow_lds(gemm_256_kernel<MODE, false>, 8 * G256_SLOT, a0);
+    hipLaunchKernelGGL((gemm_256_kernel<MODE, false>), dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  }
+}
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a8 = false, a84 = false, a86 = false;
@@ -1802,14 +1829,11 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
-    allow_lds(gemm_256_kernel<4>, 8 * G256_SLOT, a84);
-    hipLaunchKernelGGL(gemm_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+    launch_256x<4>(p, nwg, stream);
   } else if (MODE == 0 && p.out_f32 && p.accumulate && p.splitk <= 1 && p.vec_ok) {   // fp32 read-modify-write: see MODE 6
-    allow_lds(gemm_256_kernel<6>, 8 * G256_SLOT, a86);
-    hipLaunchKernelGGL(gemm_256_kernel<6>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+    launch_256x<6>(p, nwg, stream);
   } else {
-    allow_lds(gemm_256_kernel<MODE>, 8 * G256_SLOT, a8);
-    hipLaunchKernelGGL(gemm_256_kernel<MODE>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+    launch_256x<MODE>(p, nwg, stream);
   }
 }
 
@@ -1891,8 +1915,7 @@ int lmod_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, const void* b
   const long long nwg = (long long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   static bool a5 = false;
-  allow_lds(gemm_256_kernel<5>, 8 * G256_SLOT, a5);
-  hipLaunchKernelGGL(gemm_256_kernel<5>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
+  launch_256x<5>(p, nwg, stream);
   return lmod_launch_status();
 }
 

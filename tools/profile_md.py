@@ -29,7 +29,7 @@ def stats_md():
     gm = line["config"]["micro_batch_per_gpu"] * 2048
     blocks = (gm // 256) * (12288 // 256)
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
-         if "gemm_256_kernel<0>" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // 512 == blocks]
+         if "gemm_256_kernel<0" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // 512 == blocks]
     rl = line["roofline"]
     out += ["", "## Dominant kernel cross-check", "",
             f"`gemm_256_kernel<0>` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
