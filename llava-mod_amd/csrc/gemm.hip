@@ -1391,6 +1391,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef G4_DEEP
 #define G4_DEEP 1
 #endif
+#ifndef G4_B2
+#define G4_B2 1                     // two barriers per K tile (0: three, the vendor kernel's arrangement: -0.5 ... -0.9 %)
+#endif
 #ifndef G4_ABL
 #define G4_ABL 0                    // timing ablations of the deep schedule (WRONG RESULTS): 1 no barriers, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no vmcnt wait, 16 every LDS-DMA out of range (no traffic)
 #endif
@@ -1504,6 +1507,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int t = 0; t < nkt; ++t) {
     const char* sx = smem + (t & 1) * G4_STAGE + ph[1];              // this tile, k-half 1
     const char* sy = smem + ((t + 1) & 1) * G4_STAGE + ph[0];        // next tile, k-half 0
+#if G4_B2
+    // two barriers per tile: both operands' k-step-1 fragments first (MFMAs 0-30), ONE barrier frees all of X, then the 16 pieces
+    // of tile t+2 every 5 MFMAs (A 0-7, B 0-7), barrier 3 with vmcnt(10) in between
+    auto piece = [&](const int pc) { if (pc < 8) dma_a(k64_t, t + 2, pc); else dma_b(k64_t, t + 2, pc - 8); };
+#pragma unroll
+    for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 0
+      G4_MFMA(0, idx);
+      if (idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * 2048); G4_SB(); }
+      if (idx >= 16 && idx < 32 && !(idx & 1)) { fb[1][(idx - 16) >> 1] = *(const bf16x8*)(sx + bbase + ((idx - 16) >> 1) * 2048); G4_SB(); }
+      if (idx == 38) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G4_BARRIER(); G4_SB(); }
+      if (idx >= 39 && idx <= 59 && (idx - 39) % 5 == 0) { piece((idx - 39) / 5); G4_SB(); }                       // pieces 0-4
+    }
+    G4_SB();
+#pragma unroll
+    for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 1
+      G4_MFMA(1, idx);
+      if (idx <= 20 && idx % 5 == 0) { piece(5 + idx / 5); G4_SB(); }                                              // pieces 5-9
+      if (idx == 22) { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); G4_BARRIER(); G4_SB(); }
+      if (idx >= 25 && idx <= 55 && (idx - 25) % 6 == 0) { piece(10 + (idx - 25) / 6); G4_SB(); }                  // pieces 10-15
+      if (idx >= 23 && idx <= 46 && (idx - 23) % 3 != 2) {
+        const int f = ((idx - 23) / 3) * 2 + (idx - 23) % 3;
+        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * 2048);
+        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * 2048);
+        G4_SB();
+      }
+    }
+#else
 #pragma unroll
     for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 0
       G4_MFMA(0, idx);
@@ -1535,6 +1565,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         G4_SB();
       }
     }
+#endif
     G4_SB();
   }
   };
@@ -1825,7 +1856,10 @@ template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a8 = false, a84 = false, a86 = false;
   const int w = gemm_waves();
-  if (w == 4) {
+  // the 4-wave kernel (128x128 per wave, one wave per SIMD, the vendor kernel's shape and loop structure) is 2.4 % ahead of the 8-wave
+  // one on the fused SwiGLU forward at K 4096 and level at K 2048 (profiles/r03_vendor_ab.md); its multi-option MODE 0 epilogue
+  // spills, so only this launch class takes it by default
+  if (w == 4 || (w == 0 && MODE == 1 && p.K >= 4096)) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
