@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lr = (j * 4 + wave) * 8 + (lane >> 3);                      // LDS row 0..255
     voA[j] = (lr < rowsA) ? (uint32_t)((lr * p.lda + cchunk * 8) * 2) : GEMM_OOB;
     const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
-    if (MODE == 0) {
+    if (MODE != 1) {
       const int nloc = grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);          // permuted tile column
       voB[j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
     } else {       // groups 2wc / 2wc+1 = gate / up rows of output columns wc*64 .. +63
@@ -1724,11 +1724,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int x = 0; x < 16; ++x) if (cb + x < p.N) cp[x] = f2bf(p.accumulate ? bf2f(cp[x]) + v[x] : v[x]);
     }
   };
+  // MODE 7 / 4 / 6: ONE epilogue variant per instantiation (the launcher guarantees its preconditions).  With all of them behind run-time
+  // branches in MODE 0 the 256 accumulators per lane leave the register allocator no room: 109 spilled VGPRs and 1271 instead of
+  // ~1450 TF on the plain GEMM.  MODE 0 keeps every option (split-K, f32 store, bf16 accumulate, ...).
+  if constexpr (MODE == 7) G4_FOR_ALL_TILES(epi_bf16);                 // bf16 C = act(acc + bias)
+  else if constexpr (MODE == 4) G4_FOR_ALL_TILES(epi_swiglu_bwd);      // fused SwiGLU backward
+  else if constexpr (MODE == 6) G4_FOR_ALL_TILES(epi_f32_acc);         // fp32 C += acc (no bias / act / split; C and ldc 16-byte aligned)
+  else {
   if (p.act == 3) G4_FOR_ALL_TILES(epi_swiglu_bwd);
   else if (p.splitk > 1) G4_FOR_ALL_TILES(epi_partial);
   else if (!p.out_f32 && !p.accumulate) G4_FOR_ALL_TILES(epi_bf16);
   else if (p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) G4_FOR_ALL_TILES(epi_f32_acc);
   else G4_FOR_ALL_TILES(epi_generic);
+  }
 #undef G4_FOR_ALL_TILES
   if (MODE == 0 && p.splitk > 1) {
     // deterministic split-K reduction (see gemm_256_kernel): the last split to arrive adds all partials in split order
@@ -1832,7 +1840,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // LMOD_GEMM_WAVES=4 runs the 4-wave kernel everywhere (A/B runs).
 static int gemm_waves() {
   static int w = -1;
-  if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4) w = 0; }
+  if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4 && w != 44) w = 0; }      // 44: default routing + the 4-wave MODE 4 / 6 instantiations (A/B)
   return w;
 }
 template <typename KT>
@@ -1854,14 +1862,23 @@ static void launch_256x(const GemmP& p, long long nwg, hipStream_t stream) {
 }
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
-  static bool a4 = false, a8 = false, a84 = false, a86 = false;
+  static bool a4 = false, a44 = false, a46 = false, a47 = false;
   const int w = gemm_waves();
-  // the 4-wave kernel (128x128 per wave, one wave per SIMD, the vendor kernel's shape and loop structure) is 2.4 % ahead of the 8-wave
-  // one on the fused SwiGLU forward at K 4096 and level at K 2048 (profiles/r03_vendor_ab.md); its multi-option MODE 0 epilogue
-  // spills, so only this launch class takes it by default
-  if (w == 4 || (w == 0 && MODE == 1 && p.K >= 4096)) {
+  // the 4-wave kernel (128x128 per wave, one wave per SIMD, the vendor kernel's shape and loop structure) is ~2 % ahead of the 8-wave
+  // one (profiles/r03_vendor_ab.md): the launch classes that have a single-variant epilogue instantiation take it by default;
+  // split-K, k_valid batches (their XCD balancing lives in the 8-wave kernel) and the rare option mixes stay on 8 waves
+  if (w == 4 || ((w == 0 || w == 44) && MODE == 1)) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3) {     // (in-step: 1177 us per launch against 1124 us for
+    allow_lds(gemm4_kernel<4>, 2 * G4_STAGE, a44);                                       //  the 8-wave kernel's two-batch epilogue: not routed)
+    hipLaunchKernelGGL(gemm4_kernel<4>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else if ((w == 0 || w == 44) && MODE == 0 && p.splitk <= 1 && !p.k_valid && !p.out_f32 && !p.accumulate && p.act != 3) {
+    allow_lds(gemm4_kernel<7>, 2 * G4_STAGE, a47);
+    hipLaunchKernelGGL(gemm4_kernel<7>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) {   // (not routed: the 8-wave MODE 6 has the two-batch read-modify-write)
+    allow_lds(gemm4_kernel<6>, 2 * G4_STAGE, a46);
+    hipLaunchKernelGGL(gemm4_kernel<6>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation
     launch_256x<4>(p, nwg, stream);
   } else if (MODE == 0 && p.out_f32 && p.accumulate && p.splitk <= 1 && p.vec_ok) {   // fp32 read-modify-write: see MODE 6
