@@ -455,7 +455,7 @@ def main():
         sps = args.steps * B * A * world / dt
         ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
         achieved = ledger * sps / world
-        # dominant kernel (gemm_256_kernel<0>, ~51 % of GPU time in profiles/) at the shape it spends most time on —
+        # dominant kernel (the plain bf16 NT GEMM: gemm4_kernel<7>, ~28 % of GPU time in profiles/) at the shape it spends most time on —
         # the teacher's fused QKV projection — measured live with HIP events on the launch stream (torch's current stream)
         gm, gn, gk = B * 2048, 12288, 4096
         a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
@@ -507,7 +507,7 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_256_kernel<0> (bf16 NT GEMM, 256x256x64 tiles) @ teacher QKV [{gm}x{gn}x{gk}]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128; LMOD_GEMM_WAVES=8: gemm_256_kernel<0>) @ teacher QKV [{gm}x{gn}x{gk}]",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": round(gemm_ms, 4),

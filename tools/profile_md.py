@@ -28,18 +28,21 @@ def stats_md():
     # the bench's live-timed launches: gemm_256_kernel<0> with the teacher-QKV grid (128 x 48 tiles)
     gm = line["config"]["micro_batch_per_gpu"] * 2048
     blocks = (gm // 256) * (12288 // 256)
+    # (round 3: plain bf16 launches run on the 4-wave kernel, 256 threads per workgroup; older builds / LMOD_GEMM_WAVES=8: 512)
+    dom = "gemm4_kernel<7>" if any("gemm4_kernel<7>" in r["Kernel_Name"] for r in trace) else "gemm_256_kernel<0"
+    tpw = 256 if dom.startswith("gemm4") else 512
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
-         if "gemm_256_kernel<0" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // 512 == blocks]
+         if dom in r["Kernel_Name"] and int(r["Grid_Size_X"]) // tpw == blocks]
     rl = line["roofline"]
     out += ["", "## Dominant kernel cross-check", "",
-            f"`gemm_256_kernel<0>` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
-            f"trace (32 per micro-batch inside the teacher + the ones bench.py times with HIP events), average {sum(d) / len(d):.1f} us, "
+            f"`{dom}{'>' if dom.endswith('0') else ''}` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
+            f"trace (the launches bench.py times with HIP events; the models' own QKV projections run on the fused QKV + RoPE instantiation), average {sum(d) / len(d):.1f} us, "
             f"min {min(d):.1f}, max {max(d):.1f}.  bench.py's live HIP-event figure in the same run: {rl['launch_ms'] * 1e3:.1f} us "
             f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak)."]
     by = collections.defaultdict(lambda: [0, 0.0])
     for r in trace:
-        if "gemm_256_kernel" in r["Kernel_Name"]:
-            k = (r["Kernel_Name"][5:23], int(r["Grid_Size_X"]) // 512)
+        if "gemm_256_kernel" in r["Kernel_Name"] or "gemm4_kernel" in r["Kernel_Name"]:
+            k = (r["Kernel_Name"][5:23], int(r["Grid_Size_X"]) // (256 if "gemm4_kernel" in r["Kernel_Name"] else 512))
             by[k][0] += 1; by[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     out += ["", "## 256-tile GEMM launches by grid size (workgroups; 256 CUs => `waves` rounds)", "",
             "| kernel | workgroups | rounds | calls | total ms |", "|---|---|---|---|---|"]
@@ -68,13 +71,14 @@ def pmc_md():
            "Per-dispatch averages.  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles; "
            "`SQ_VALU_MFMA_BUSY_CYCLES` counts cycles summed over the 1024 SIMDs; `GRBM_GUI_ACTIVE` is summed over the 8 XCDs.", ""]
     g = pmc("gemm_sq"); f = pmc("gemm_fetch"); w = pmc("gemm_write")
-    k = next(x for x in g if "gemm_256" in x)
+    k = next(x for x in g if "gemm4_kernel" in x or "gemm_256" in x)      # whichever kernel the plain bf16 GEMM launch runs on
+    kname = k.replace("void ", "").split("(")[0]
     c, us = g[k]
     fetch_kb, write_kb = f[k][0]["FETCH_SIZE"], w[k][0]["WRITE_SIZE"]
     M, N, Kd = 32768, 12288, 4096
     algo = (M * Kd + N * Kd + M * N) * 2
     clk = c["GRBM_GUI_ACTIVE"] / 8 / us / 1e3
-    out += [f"## `gemm_256_kernel<0>` at the teacher QKV shape [{M} x {N} x {Kd}] (`python tools/gemm_one.py`)", "",
+    out += [f"## `{kname}` at the teacher QKV shape [{M} x {N} x {Kd}] (`python tools/gemm_one.py`)", "",
             f"* duration under the counter passes: {us:.0f} us ({2.0 * M * N * Kd / us / 1e6:.0f} TFLOP/s; counter collection and its lower "
             f"clock cost ~10 % against the un-profiled {2.0 * M * N * Kd / 1e12:.2f} TFLOP launch in bench.py)",
             f"* effective clock: GRBM_GUI_ACTIVE / 8 / duration = **{clk:.2f} GHz** (peak 2.4): the chip is power-limited under this kernel",
@@ -111,7 +115,7 @@ def pmc_md():
                        f"{c['SQ_INSTS_SALU'] / 1e6:.2f} | {c['SQ_INSTS_VMEM_RD'] / 1e6:.2f} | {c['SQ_INSTS_VALU'] / max(1.0, c['SQ_INSTS_MFMA']):.2f} | "
                        f"{c['SQ_ACTIVE_INST_VALU'] / 1e6:.1f} | {c['SQ_ACTIVE_INST_LDS'] / 1e6:.1f} | {c['SQ_WAIT_INST_LDS'] / 1e6:.1f} |")
     open(dst + "_pmc.md", "w").write("\n".join(out) + "\n")
-    json.dump({"kernel": "gemm_256_kernel<0>", "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
+    json.dump({"kernel": kname, "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
                "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md §HBM"},
               open(dst + "_gemm_traffic.json", "w"), indent=1)
