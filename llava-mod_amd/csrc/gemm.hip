@@ -1649,10 +1649,111 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      const int c = col0 + wc * 128 + gq * 64 + g * 16 + x;
-      biav[gq][x] = (p.bias && c < p.N) ? bf2f(p.bias[min(c, p.N - 1)]) : 0.f;
+    for (int x = 0; x < 16; ++x) biav[gq][x] = 0.f;
+  if (p.bias) {             // clamped, unconditional loads: 32 in flight, one wait (a per-element condition made each its own round trip)
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int c = col0 + wc * 128 + gq * 64 + g * 16 + x;
+        const float bv = bf2f(p.bias[min(c, p.N - 1)]);
+        biav[gq][x] = (c < p.N) ? bv : 0.f;
+      }
+  }
+  if constexpr (MODE == 5) {
+    // fused q/k/v projection + bias + RoPE (lmod_gemm_qkv_rope_bf16, hd 128).  A wave column is 128 output columns = ONE head, and a
+    // lane holds columns g*16 .. +15 of both 64-column halves: the rotate_half partner of feature f (f + 64 / f - 64) sits in the
+    // SAME lane (acc[mt][nt] and acc[mt][nt + 4]) — no exchange through LDS and no barrier, unlike the 8-wave kernel's epilogue.
+    // Same roundings as GEMM + bias -> bf16, then rope_kernel.  N % 128 == 0 (host-checked).  Memory order as in the other
+    // epilogues: positions first, then cos / sin of two row tiles at a time, issued ahead of the previous two's stores.
+    bf16_t* Cb5 = (bf16_t*)p.C + (long long)bz * p.sC;
+    const int cb = col0 + wc * 128 + g * 16;
+    if (cb >= p.N) return;
+    auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+    auto own = [&](const int mt, const int gq, u32x4& lo, u32x4& hi) {      // bf16(acc + bias): features gq*64 + g*16 + 0..7 | 8..15
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[nt * 4 + q] = acc[mt][gq * 4 + nt][q] + biav[gq][nt * 4 + q];
+      lo = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      hi = (u32x4){pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+    };
+    if (col0 >= p.rope_cols) {                        // V columns: bias only (workgroup-uniform: rope_cols is a multiple of 256)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = rowof(mt);
+        if (row >= Mv) continue;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          u32x4 lo, hi;
+          own(mt, gq, lo, hi);
+          bf16_t* op = Cb5 + (long long)row * p.ldc + cb + gq * 64;
+          st_c(op, lo);
+          st_c(op + 8, hi);
+        }
+      }
+      return;
     }
+    int ps[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) ps[mt] = p.rope_pos[(long long)bz * p.M + min(rowof(mt), p.M - 1)];
+    u32x4 CC[4][2][2][2], SS[4][2][2][2];             // [batch of 2 row tiles][m][gq][hx]
+    auto ld = [&](const int b2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bf16_t* cp = p.rope_cos + (long long)ps[b2 * 2 + m] * 128 + g * 16;
+        const bf16_t* sp = p.rope_sin + (long long)ps[b2 * 2 + m] * 128 + g * 16;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int hx = 0; hx < 2; ++hx) {
+            CC[b2][m][gq][hx] = *(const u32x4*)(cp + gq * 64 + hx * 8);
+            SS[b2][m][gq][hx] = *(const u32x4*)(sp + gq * 64 + hx * 8);
+          }
+      }
+    };
+    auto cmp = [&](const int b2) {                    // results replace CC
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int mt = b2 * 2 + m;
+        u32x4 x1[2], x2[2];                           // first half (features < 64) / second half, [hx]
+        own(mt, 0, x1[0], x1[1]);
+        own(mt, 1, x2[0], x2[1]);
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          u32x4 o1, o2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a0 = bflo(x1[hx][k]), a1 = bfhi(x1[hx][k]), b0 = bflo(x2[hx][k]), b1 = bfhi(x2[hx][k]);
+            const uint32_t c1 = CC[b2][m][0][hx][k], s1 = SS[b2][m][0][hx][k], c2 = CC[b2][m][1][hx][k], s2 = SS[b2][m][1][hx][k];
+            // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin  (rope_kernel's roundings)
+            o1[k] = pack2bf(bfround(a0 * bflo(c1)) + bfround(-b0 * bflo(s1)), bfround(a1 * bfhi(c1)) + bfround(-b1 * bfhi(s1)));
+            o2[k] = pack2bf(bfround(b0 * bflo(c2)) + bfround(a0 * bflo(s2)), bfround(b1 * bfhi(c2)) + bfround(a1 * bfhi(s2)));
+          }
+          CC[b2][m][0][hx] = o1;
+          CC[b2][m][1][hx] = o2;
+        }
+      }
+    };
+    auto pin = [&](const int b2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        asm volatile("" : "+v"(CC[b2][m][0][0]), "+v"(CC[b2][m][0][1]), "+v"(CC[b2][m][1][0]), "+v"(CC[b2][m][1][1]) : : "memory");
+    };
+    auto st = [&](const int b2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int row = rowof(b2 * 2 + m);
+        if (row >= Mv) continue;
+        bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) { st_c(op + gq * 64, CC[b2][m][gq][0]); st_c(op + gq * 64 + 8, CC[b2][m][gq][1]); }
+      }
+    };
+    ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); pin(1); ld(2); st(1); cmp(2); pin(2); ld(3); st(2); cmp(3); st(3);
+    return;
+  }
   auto epi_bf16 = [&](const int gq, const int mt) {          // the common case: bf16 C = act(acc + bias), vector stores
     const int cb = col0 + wc * 128 + gq * 64 + g * 16;
     const int row = row0 + wr * 128 + mt * 16 + li;
@@ -1865,8 +1966,9 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a44 = false, a46 = false, a47 = false;
   const int w = gemm_waves();
   // the 4-wave kernel (128x128 per wave, one wave per SIMD, the vendor kernel's shape and loop structure) is ~2 % ahead of the 8-wave
-  // one (profiles/r03_vendor_ab.md): the launch classes that have a single-variant epilogue instantiation take it by default;
-  // split-K, k_valid batches (their XCD balancing lives in the 8-wave kernel) and the rare option mixes stay on 8 waves
+  // one at K >= 4096 and level or slightly behind at K 2048, depending on N (profiles/r03_vendor_ab.md; in the step: -0.5 % / -0.7 % of
+  // the plain / fused-SwiGLU kernel time): the plain bf16 store and the fused SwiGLU forward take it by default; split-K, k_valid
+  // batches (their XCD balancing lives in the 8-wave kernel) and the rare option mixes stay on 8 waves
   if (w == 4 || ((w == 0 || w == 44) && MODE == 1)) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
@@ -1965,8 +2067,15 @@ int lmod_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, const void* b
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   const long long nwg = (long long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
-  static bool a5 = false;
-  launch_256x<5>(p, nwg, stream);
+  // 4-wave variant (LMOD_GEMM_WAVES=4 / 44): a wave column is one 128-feature head, the rotate_half partner sits in the same lane (no LDS exchange)
+  static bool a45 = false;
+  const int w = gemm_waves();
+  if ((w == 4 || w == 44) && (N & 127) == 0) {      // (A/B only: level with the 8-wave epilogue at the student's shape, not yet measured in the step)
+    allow_lds(gemm4_kernel<5>, 2 * G4_STAGE, a45);
+    hipLaunchKernelGGL(gemm4_kernel<5>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else {
+    launch_256x<5>(p, nwg, stream);
+  }
   return lmod_launch_status();
 }
 
