@@ -1293,24 +1293,23 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 }
 
 // =============================================================================================
-// 256 x 256 x 64 tile, FOUR waves (2 x 2), 128 x 128 output per wave, ONE wave per SIMD — the step's GEMM.
+// 256 x 256 x 64 tile, FOUR waves (2 x 2), 128 x 128 output per wave, ONE wave per SIMD.  By default the plain bf16 GEMM launches
+// (MODE 7) and the fused SwiGLU forward (MODE 1) run on it; see launch_256.
 //
-// Why: the chip is power-limited under dense bf16 work (profiles/r01_final_mfma_spin.md), so what counts is energy
-// per flop.  With 128x128 per wave every LDS operand fragment feeds 8 MFMAs (LDS reads 128 KB per K tile instead of
-// the 192 KB of the 8-wave 128x64 layout), half as many waves issue, and there is ONE barrier per K tile.
-// Registers: the 64 accumulator tiles (256 registers) are pinned to the AGPR half of the unified file through
-// inline-asm MFMAs with "+a" operands (left alone, hipcc shuttles them through a[0:3] with ~1000 v_accvgpr moves per
-// K tile); operand fragments are double-buffered in VGPRs (2 x 64).
-// Schedule per K tile (two k-steps of 64 MFMAs): the fragments of the NEXT k-step are read, and the LDS-DMA pieces
-// of tile t+2 issued, one instruction every two MFMAs (with a single wave per SIMD anything that is not in an MFMA
-// shadow is lost time).  Stage t&1 is re-filled right after the mid-tile barrier, which every wave reaches having
-// finished its reads of that stage and with its own pieces of tile t+1 landed (vmcnt(0)): a full tile of latency cover.
-// LDS: 2 stages x (A [256][64] + B [256][64]) bf16 = 128 KiB, rows XOR-swizzled as in the 128 kernel, B rows permuted
-// so a lane ends with 16 contiguous output columns per 64-column group.
-// MODE 0: C = act(A B^T + b) with every option of lmod_gemm_bf16_nt (grouped, k_valid, f32 / accumulate, split-K,
-//         fused SwiGLU backward epilogue).  MODE 1: fused SwiGLU forward (see gemm_256_kernel<1>): an N tile is 128
-//         output columns; wave column wc takes 64 of them, its first 64 LDS B rows are the gate rows and the next 64
-//         the matching up rows, so a lane owns 16 gate and the same 16 up columns.
+// Why this shape: with 128x128 per wave every LDS operand fragment feeds 8 MFMAs (LDS reads 128 KB per K tile instead of the 192 KB
+// of the 8-wave 128x64 layout) and half as many waves issue.  It is also the shape of hipBLASLt's hand-written gfx950 kernel, whose
+// loop structure the main loop below follows (profiles/r03_vendor_ab.md).
+// Registers: the 64 accumulator tiles (256 registers) are pinned to the AGPR half of the unified file through inline-asm MFMAs with
+// "+a" operands (left alone, hipcc shuttles them through a[0:3] with ~1000 v_accvgpr moves per K tile); operand fragments are
+// double-buffered in VGPRs (2 x 64).  With a single wave per SIMD anything that is not in an MFMA shadow is lost time: every
+// non-MFMA instruction of the loop sits behind a named MFMA (see the schedule at the loop).
+// LDS: 2 stages x (A [256][64] + B [256][64]) bf16 = 128 KiB, rows XOR-swizzled as in the 128 kernel, B rows permuted so a lane ends
+// with 16 contiguous output columns per 64-column group.
+// MODE 0: C = act(A B^T + b) with every option of lmod_gemm_bf16_nt (grouped, k_valid, f32 / accumulate, split-K, fused SwiGLU
+//         backward) behind run-time branches — 109 spilled VGPRs in that epilogue, so the hot option sets have their own instantiations:
+// MODE 7: bf16 C = act(acc + bias).  MODE 4: fused SwiGLU backward.  MODE 6: fp32 C += acc.  MODE 5: fused q/k/v + bias + RoPE.
+// MODE 1: fused SwiGLU forward (see gemm_256_kernel<1>): an N tile is 128 output columns; wave column wc takes 64 of them, its first
+//         64 LDS B rows are the gate rows and the next 64 the matching up rows, so a lane owns 16 gate and the same 16 up columns.
 // =============================================================================================
 #define G4_STAGE 65536
 template <int MODE>
@@ -1453,17 +1452,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);
   }
 #else
-  // Schedule (G4_DEEP, the default): what hipBLASLt's hand-written gfx950 kernel of the same shape does (4 waves, 128x128 per
-  // wave, 256x256x64 tile; its main loop read from the library's code object with llvm-objdump — 1587 TF on the teacher QKV
-  // shape against 1270 TF for this kernel's previous one-barrier schedule, which waited vmcnt(0) at mid tile: 0.5-0.75 tiles of
-  // cover for the LDS-DMA).  Per K tile t (stage X = t & 1 holds it, stage Y holds t + 1, k-step-0 fragments are in registers):
-  //   k-step 0, MFMAs 0-15: the A fragments of k-step 1 are read; at MFMA 36 every wave has them: barrier 1 frees X's A half
-  //             MFMAs 37-52: LDS-DMA of A(t+2) into X, interleaved with the reads of the B fragments of k-step 1
-  //             end: those reads have landed: barrier 2 frees X's B half
-  //   k-step 1, MFMAs 1-15: LDS-DMA of B(t+2) into X
-  //             MFMA 28: vmcnt(16) — everything issued before this tile's 16 pieces, i.e. all of tile t+1 — barrier 3
-  //             MFMAs 29-59: the k-step-0 fragments of tile t+1 are read from Y
-  // A piece has 1.0-1.4 tiles to land instead of 0.5-0.75, for two more barriers per tile.
+  // Schedule (G4_DEEP, the default; G4_DEEP=0 is the round-1 loop: one barrier at mid tile behind vmcnt(0), 0.5-0.75 tiles of cover for
+  // the LDS-DMA, 1270 TF).  It follows hipBLASLt's hand-written gfx950 kernel of the same shape (its main loop read from the library's
+  // code object with llvm-objdump: 1587 TF on the teacher QKV shape).  Per K tile t — stage X = t & 1 holds it, stage Y holds t + 1,
+  // the k-step-0 fragments are in registers — with G4_B2 (two barriers, the default):
+  //   k-step 0  MFMAs 0-30   both operands' k-step-1 fragments are read (one ds_read behind every second MFMA)
+  //             MFMA 38      lgkmcnt(0) + barrier 1: every wave holds ALL of tile t in registers => stage X is free
+  //             MFMAs 39-59  LDS-DMA pieces 0-4 of tile t+2 into X, one every 5 MFMAs (four waves share one address unit)
+  //   k-step 1  MFMAs 0-20   pieces 5-9
+  //             MFMA 22      vmcnt(10) — everything older than this tile's 10 pieces so far, i.e. all of tile t+1 — + barrier 2
+  //             MFMAs 23-46  the k-step-0 fragments of tile t+1 are read from Y (two behind every three MFMAs, the last one 12 MFMAs
+  //                          ahead of the loop end); pieces 10-15 in the free slots (25, 31, ..., 55)
+  // A piece has 1.0-1.4 tiles to land.  G4_B2=0 keeps the vendor kernel's three barriers (A half and B half freed separately).
   // K64 (the reduction length is a multiple of 64: every shape of the step but the MoE experts' routed-row counts): a tile is wholly
   // live or wholly past the end, so "past the end" is a SCALAR choice of descriptor (zero records: every lane out of range, no
   // traffic) instead of one v_cndmask per LDS-DMA in the MFMA gaps.
