@@ -5,7 +5,6 @@ compute in this file (torch only allocates device memory).  Tensors are bf16 unl
 """
 import torch
 
-from . import _hip
 from ._hip import call, ptr
 
 BF16 = torch.bfloat16

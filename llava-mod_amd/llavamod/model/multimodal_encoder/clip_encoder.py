@@ -9,7 +9,6 @@ Only the layers up to `select_layer` are executed (hidden_states[-2] => 23 of 24
 
 Parameter names are HF 4.37's (`image_tower.vision_model.…`) so LLaVA-MoD checkpoints load by name.
 """
-from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
