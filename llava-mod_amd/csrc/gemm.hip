@@ -1829,8 +1829,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // branches in MODE 0 the 256 accumulators per lane leave the register allocator no room: 109 spilled VGPRs and 1271 instead of
   // ~1450 TF on the plain GEMM.  MODE 0 keeps every option (split-K, f32 store, bf16 accumulate, ...).
   if constexpr (MODE == 7) G4_FOR_ALL_TILES(epi_bf16);                 // bf16 C = act(acc + bias)
-  else if constexpr (MODE == 4) G4_FOR_ALL_TILES(epi_swiglu_bwd);      // fused SwiGLU backward
-  else if constexpr (MODE == 6) G4_FOR_ALL_TILES(epi_f32_acc);         // fp32 C += acc (no bias / act / split; C and ldc 16-byte aligned)
+  else if constexpr (MODE == 4) {
+    // fused SwiGLU backward, memory order as in gemm_256_kernel<4>: the [gate | up] loads of 4 of the 16 pieces at a time, each batch's loads issued
+    // AHEAD of the previous batch's stores (8 at a time spilled beside the 256 accumulators) (piece = (gq, mt): 16 rows x 64 columns; a lane holds 16 columns of it)
+    const int Mz4 = min((Mv + 7) & ~7, p.M);
+    auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+    auto colof = [&](int gq) { return col0 + wc * 128 + gq * 64 + g * 16; };
+    u32x4 G[4][4][2], U[4][4][2];                    // [batch][piece in batch: gq * 2 + (mt & 1)][hx]; batch = mt >> 1
+    auto ld = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+        const bf16_t* gp = (const bf16_t*)p.C2 + (long long)bz * p.sC2 + (long long)min(rowof(mt), p.M - 1) * p.ldc2 + min(colof(gq), p.N - 16);
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { G[b][pc][hx] = *(const u32x4*)(gp + hx * 8); U[b][pc][hx] = *(const u32x4*)(gp + p.N + hx * 8); }
+      }
+    };
+    auto cmp = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          float d8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d8[e] = acc[mt][gq * 4 + hx * 2 + (e >> 2)][e & 3];
+          u32x4 og, ou;
+          swiglu_bwd8(d8, G[b][pc][hx], U[b][pc][hx], og, ou);
+          G[b][pc][hx] = og; U[b][pc][hx] = ou;
+        }
+      }
+    };
+    auto pin = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) asm volatile("" : "+v"(G[b][pc][0]), "+v"(G[b][pc][1]), "+v"(U[b][pc][0]), "+v"(U[b][pc][1]) : : "memory");
+    };
+    auto st = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1), row = rowof(mt), cb = colof(gq);
+        if (cb >= p.N || row >= Mv) continue;
+        bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = G[b][pc][hx]; *(u32x4*)(op + p.N + hx * 8) = U[b][pc][hx]; }
+      }
+    };
+    ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); pin(1); ld(2); st(1); cmp(2); pin(2); ld(3); st(2); cmp(3); st(3);
+    if (Mz4 != Mv) {                                 // rows Mv .. roundup8(Mv)-1 are zeroed (a k_valid wgrad reads whole 8-row chunks)
+#pragma unroll
+      for (int pc = 0; pc < 16; ++pc) {
+        const int gq = pc >> 3, mt = pc & 7, row = rowof(mt), cb = colof(gq);
+        if (cb >= p.N || row < Mv || row >= Mz4) continue;
+        bf16_t* op = (bf16_t*)p.C + (long long)bz * p.sC + (long long)row * p.ldc + cb;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
+      }
+    }
+  } else if constexpr (MODE == 6) {
+    // fp32 C += acc (no bias / act / split; C and ldc 16-byte aligned, N % 16 == 0 not required: whole 4-column groups), four
+    // batches of 4 pieces as above
+    auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+    auto colof = [&](int gq) { return col0 + wc * 128 + gq * 64 + g * 16; };
+    const bool vec = (p.N & 3) == 0;                 // (N % 4 != 0: the generic piece-by-piece variant)
+    if (!vec) { G4_FOR_ALL_TILES(epi_f32_acc); }
+    else {
+      f32x4 R[4][4][4];
+      auto ld = [&](const int b) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+          const float* cp = (const float*)Cb + (long long)min(rowof(mt), p.M - 1) * p.ldc;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) R[b][pc][x] = *(const f32x4*)(cp + min(colof(gq) + 4 * x, p.N - 4));
+        }
+      };
+      auto add = [&](const int b) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) R[b][pc][x] += acc[mt][gq * 4 + x];
+        }
+      };
+      auto pin = [&](const int b) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) asm volatile("" : "+v"(R[b][pc][0]), "+v"(R[b][pc][1]), "+v"(R[b][pc][2]), "+v"(R[b][pc][3]) : : "memory");
+      };
+      auto st = [&](const int b) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          const int gq = pc >> 1, mt = b * 2 + (pc & 1), row = rowof(mt), cb = colof(gq);
+          if (row >= Mv) continue;
+          float* cp = (float*)Cb + (long long)row * p.ldc + cb;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) if (cb + 4 * x + 4 <= p.N) *(f32x4*)(cp + 4 * x) = R[b][pc][x];
+        }
+      };
+      ld(0); add(0); pin(0); ld(1); st(0); add(1); pin(1); ld(2); st(1); add(2); pin(2); ld(3); st(2); add(3); st(3);
+    }
+  }
   else {
   if (p.act == 3) G4_FOR_ALL_TILES(epi_swiglu_bwd);
   else if (p.splitk > 1) G4_FOR_ALL_TILES(epi_partial);
@@ -2067,10 +2164,10 @@ int lmod_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, const void* b
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   const long long nwg = (long long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
-  // 4-wave variant (LMOD_GEMM_WAVES=4 / 44): a wave column is one 128-feature head, the rotate_half partner sits in the same lane (no LDS exchange)
+  // 4-wave kernel by default: a wave column is one 128-feature head, the rotate_half partner sits in the same lane (no LDS exchange)
   static bool a45 = false;
   const int w = gemm_waves();
-  if ((w == 4 || w == 44) && (N & 127) == 0) {      // (A/B only: level with the 8-wave epilogue at the student's shape, not yet measured in the step)
+  if ((w == 0 || w == 4 || w == 44) && (N & 127) == 0) {   // +2 % (student shape) ... +3 % (teacher shape) over the 8-wave kernel's LDS-exchange epilogue, bit-identical
     allow_lds(gemm4_kernel<5>, 2 * G4_STAGE, a45);
     hipLaunchKernelGGL(gemm4_kernel<5>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else {
