@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRAINABLE = 2035388416        # config 2: 12 dense + 12x4-expert FFNs, 12 routers, projector (dense2sparse_distillation.sh:27-42)
 
 
-def _run(*extra):
+def _run(*extra, gpus=2):
     env = dict(os.environ, LMOD_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)                                       # plain start: no launcher environment
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", *extra],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--launch-check", *extra],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -62,3 +62,22 @@ def test_bench_self_launch_variants(extra, check):
         c = plan["collectives_per_step"]
         assert c["reduce_scatter"]["calls"] == 0 and c["all_reduce"]["bytes"] == 2 * TRAINABLE
         assert out["optimizer_state_elems_rank0"] == out["grad_buffer_elems"]
+
+
+def test_bench_self_launch_world4_expert_parallel_pairs_times_expert_data_parallel_pairs():
+    """World 4, ep_size 2, 4 experts: ranks {0,1} and {2,3} are expert-parallel pairs (2 experts per rank), ranks {0,2} and {1,3} hold
+    the SAME experts — their gradients are reduced over those pairs (groups of 2), everything else over all four.  The plan of
+    this launch equals what the same command issued on hardware (profiles/r03_ranks_share_one_gpu_gloo.jsonl, 4th line)."""
+    out = _run("--ep", "2", "--experts", "4", gpus=4)
+    ex = out["exchange"]
+    plan = ex["plan"]
+    c = plan["collectives_per_step"]
+    assert out["n_gpus"] == 4 and ex["world_seen_by_backend"] == 4 and ex["ep_size"] == 2 and plan["rank_local_params"] == 0
+    expert_local = 12 * 2 * 3 * 2048 * 5504                      # 12 MoE layers x 2 local experts x (gate + up + down)
+    dense = out["trainable_params"] - expert_local - plan["replicated_params"]
+    assert plan["sharded_params"] == dense + expert_local
+    assert c["reduce_scatter"]["calls"] == c["all_gather"]["calls"] == 12 * 2 + 12 * 2 + 2
+    # a reduce-scatter hands the whole local span to the collective: 4 bytes per element of dense and of local expert spans alike
+    assert c["reduce_scatter"]["bytes"] == 4 * plan["sharded_params"] == 4894752768
+    # optimizer state of rank 0: 1/4 of the dense spans, 1/2 of its experts' spans (the expert-data-parallel group has 2 members)
+    assert out["optimizer_state_elems_rank0"] == dense // 4 + expert_local // 2 + plan["replicated_params"] == 508923904
