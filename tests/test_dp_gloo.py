@@ -350,3 +350,94 @@ def test_two_rank_gloo_gradient_allreduce():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, "ok"), (1, "ok")]
+
+
+def _edp_worker(rank, world, port, q):
+    """World 4, ep_size 2: expert-parallel pairs {0,1}, {2,3}; expert-data-parallel pairs {0,2}, {1,3}.  A dense span is summed over all
+    four ranks, an expert span over the two ranks that hold the same experts; with ZeRO-2 the owned chunk is 1/4 resp. 1/2 of the span;
+    the clipped AdamW step on the shards equals the unsharded one and equals a single-process AdamW on the summed gradients."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")
+    from llavamod.engine import DataParallel, GradBuffer, HipAdamW, init_distributed
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2DecoderLayer, init_normal_
+    from llavamod.model.moe_layer import MoE
+    _cpu_kernels()
+    init_distributed()
+    ep = 2
+
+    def build():
+        cfg = Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1)
+        layer = Qwen2DecoderLayer(cfg, "cpu")
+        layer.mlp = MoE(64, layer.mlp, num_experts=4, ep_size=ep, k=2, capacity_factor=1.5, min_capacity=0)
+        init_normal_(layer, 0.02, 0)
+        for n, p in layer.named_parameters():
+            p.requires_grad = ("mlp" in n) or any(t in n for t in ("q_proj", "k_proj", "v_proj"))
+        return layer
+
+    def grads_of(r, numel, step):                              # what rank r puts into its gradient buffer
+        i = torch.arange(numel, dtype=torch.float32)
+        return torch.sin(i * 0.37 + step) * (0.5 + r) + 0.1 * r
+
+    def run(zero2):
+        layer = build()
+        gb = GradBuffer(layer)
+        dp = DataParallel(bucket_bytes=4096, zero2=zero2, min_shard_numel=1).attach(gb, ep_size=ep)
+        opt = HipAdamW(gb, lr=1e-2, weight_decay=0.01, dp=dp, max_grad_norm=1.0)
+        seen = {}
+        for step in range(2):
+            gb.zero()
+            gb.flat.copy_(grads_of(rank, gb.numel, step))
+            dp.finish()
+            if step == 0:                                      # the exchanged gradient of every span, on the chunk this rank owns
+                for (kind, obj, n), off in zip(gb.spans, gb.offsets):
+                    info = dp.plan[(id(obj), kind)]
+                    peers = [r for r in range(world) if r % ep == rank % ep] if info["is_expert"] else list(range(world))
+                    assert info["gsize"] == len(peers), (kind, info["is_expert"], info["gsize"])
+                    lo, hi = info["lo"], info["hi"]
+                    if zero2 and info["sharded"]:
+                        assert hi - lo == n // len(peers) and lo == off + peers.index(rank) * (n // len(peers))
+                    exp = sum(grads_of(r, gb.numel, 0)[lo:hi] for r in peers)
+                    assert torch.allclose(gb.flat[lo:hi], exp, atol=1e-5), (kind, info["is_expert"], zero2)
+                    seen[info["is_expert"]] = seen.get(info["is_expert"], 0) + 1
+            opt.step(grad_scale=1.0 / world, clear_grads=True)
+        assert seen.get(True, 0) == 2 and seen.get(False, 0) >= 2          # stacked expert gate/up + down; router, q/k/v weight + bias
+        return layer, float(opt.grad_norm)
+
+    a, na = run(False)
+    b, nb = run(True)
+    assert abs(na - nb) <= 1e-5 * abs(na) and na > 1.0                       # global-norm clipping was active and agrees
+    # sums of FOUR fp32 terms depend on the order (gloo's all-reduce and reduce-scatter add in different orders), so the clip
+    # coefficient and the masters differ in their last bits and a bf16 weight may land on the other side of a rounding boundary:
+    # at most one bf16 ulp, on a handful of elements (world 2 — order-free sums — is checked for exact equality above)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        dd = (pa.float() - pb.float()).abs()
+        if pa.dtype == torch.float32:
+            assert float(dd.max()) <= 1e-6, n
+        else:
+            assert float((dd > 0).float().mean()) <= 2e-3 and bool((dd <= pa.float().abs() * 2 ** -7 + 1e-12).all()), (n, float(dd.max()))
+    # the ranks of an expert-data-parallel pair hold identical experts after the step; the two pairs hold different ones
+    w = torch.cat([p.detach().float().reshape(-1) for n, p in b.named_parameters() if "deepspeed_experts" in n])
+    allw = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(allw, w)
+    assert torch.equal(allw[0], allw[2]) and torch.equal(allw[1], allw[3])
+    d = torch.cat([p.detach().float().reshape(-1) for n, p in b.named_parameters() if "deepspeed_experts" not in n and p.requires_grad])
+    alld = [torch.zeros_like(d) for _ in range(world)]
+    dist.all_gather(alld, d)
+    assert all(torch.equal(alld[0], x) for x in alld[1:])                    # dense weights: identical everywhere
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_four_rank_gloo_expert_data_parallel_groups():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_edp_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(4))
+    assert got == [(r, "ok") for r in range(4)]
