@@ -81,3 +81,20 @@ def test_bench_self_launch_world4_expert_parallel_pairs_times_expert_data_parall
     assert c["reduce_scatter"]["bytes"] == 4 * plan["sharded_params"] == 4894752768
     # optimizer state of rank 0: 1/4 of the dense spans, 1/2 of its experts' spans (the expert-data-parallel group has 2 members)
     assert out["optimizer_state_elems_rank0"] == dense // 4 + expert_local // 2 + plan["replicated_params"] == 508923904
+
+
+def test_bench_self_launch_world8_config3_and_config5():
+    """The two 8-GPU configurations of BASELINE.json as the driver starts them (`python bench.py --gpus 8 [...]`): config 3 (data
+    parallel, ZeRO-2) and config 5 (8 experts, ep_size 8: one expert of every MoE layer per rank, nothing to reduce them with)."""
+    out = _run(gpus=8)
+    plan = out["exchange"]["plan"]
+    assert out["n_gpus"] == 8 and out["exchange"]["world_seen_by_backend"] == 8 and plan["rank_local_params"] == 0
+    assert plan["sharded_params"] + plan["replicated_params"] == TRAINABLE
+    assert out["optimizer_state_elems_rank0"] == plan["sharded_params"] // 8 + plan["replicated_params"]
+    out = _run("--ep", "8", "--experts", "8", gpus=8)
+    plan = out["exchange"]["plan"]
+    one_expert_per_layer = 12 * 3 * 2048 * 5504
+    assert out["exchange"]["ep_size"] == 8 and plan["rank_local_params"] == one_expert_per_layer
+    assert plan["sharded_params"] + plan["replicated_params"] + plan["rank_local_params"] == out["trainable_params"]
+    assert out["optimizer_state_elems_rank0"] == plan["sharded_params"] // 8 + plan["replicated_params"] + one_expert_per_layer
+    assert plan["collectives_per_step"]["reduce_scatter"]["calls"] == 12 * 2 + 2        # dense FFN pairs + projector; experts stay local
