@@ -1311,7 +1311,22 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 // MODE 1: fused SwiGLU forward (see gemm_256_kernel<1>): an N tile is 128 output columns; wave column wc takes 64 of them, its first
 //         64 LDS B rows are the gate rows and the next 64 the matching up rows, so a lane owns 16 gate and the same 16 up columns.
 // =============================================================================================
-#define G4_STAGE 65536
+#ifndef G4_PAD
+#define G4_PAD 0                    // 1: hipBLASLt's LDS image — source addresses LINEAR inside a 128-byte row (no XOR on the
+#endif                              //    LDS-DMA source), 16 bytes of padding behind every 1 KiB piece, 2-way conflicts on the fragment reads
+#define G4_PIECE (G4_PAD ? 1040 : 1024)
+#define G4_STAGE (64 * G4_PIECE)
+#ifndef G4_ASM
+#define G4_ASM (!G4_PAD)              // the K loop as one hand-placed asm statement (XOR layout only)
+#endif
+#if G4_ASM
+#ifndef G4_ASM_HEADER
+#define G4_ASM_HEADER "gemm4_loop_asm.h"
+#endif
+#include G4_ASM_HEADER
+#endif
+#define G4_BOFF (32 * G4_PIECE)
+#define G4_FSTR (G4_PAD ? 128 : 2048)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
@@ -1361,11 +1376,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
 
   // staging: piece j of wave w fills LDS rows (j*4 + w)*8 + (lane>>3), physical chunk lane&7 (logical chunk ^ row&7)
-  const int cchunk = (lane & 7) ^ (lane >> 3);
+  const int cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
   uint32_t voA[8], voB[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+#if G4_PAD   // physical row p of a 128-row group holds logical row (p & 7) * 16 + (p >> 3): a lane's 8 fragments sit 128 bytes apart
+    const int lrp = (j * 4 + wave) * 8 + (lane >> 3), p128 = lrp & 127;
+    const int lr = (lrp & ~127) + (p128 & 7) * 16 + (p128 >> 3);
+#else
     const int lr = (j * 4 + wave) * 8 + (lane >> 3);                      // LDS row 0..255
+#endif
     voA[j] = (lr < rowsA) ? (uint32_t)((lr * p.lda + cchunk * 8) * 2) : GEMM_OOB;
     const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
     if (MODE != 1) {
@@ -1384,8 +1404,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#if G4_PAD
+  const int abase = (wr * 16 + li) * G4_PIECE, bbase = G4_BOFF + (wc * 16 + li) * G4_PIECE;
+  const int ph[2] = {g * 16, (4 + g) * 16};
+#else
   const int abase = (wr * 128 + li) * 128, bbase = 32768 + (wc * 128 + li) * 128;
   const int ph[2] = {((g) ^ (li & 7)) * 16, ((4 + g) ^ (li & 7)) * 16};
+#endif
   bf16x8 fa[2][8], fb[2][8];
 #ifndef G4_DEEP
 #define G4_DEEP 1
@@ -1399,10 +1424,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define G4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
   auto stage_piece = [&](int t, int j) {                   // tiles past the end are fully out of bounds: zero fill, no traffic
     const int k0 = t * 64;
-    char* dst = smem + (t & 1) * G4_STAGE + wave * 1024;
+    char* dst = smem + (t & 1) * G4_STAGE + wave * G4_PIECE;
     const bool dead = (k0 + cchunk * 8 >= Kv);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + G4_BOFF + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
   };
 #if !G4_DEEP
   // one k-step: 64 MFMAs on (fa[cur], fb[cur]); in their shadow the fragments of the next k-step (stage ts, k-half kn) are
@@ -1410,21 +1435,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto kstep = [&](const int cur, const int ts, const int kn, const bool dma, const int td) {
     const char* s = smem + (ts & 1) * G4_STAGE + ph[kn];
     const int k0 = td * 64;
-    char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
+    char* dst = smem + (td & 1) * G4_STAGE + wave * G4_PIECE;
     const bool dead = (k0 + cchunk * 8 >= Kv);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(fb[cur][nt]), "v"(fa[cur][mt]));
-        if (nt == 1) { fa[cur ^ 1][mt] = *(const bf16x8*)(s + abase + mt * 2048); __builtin_amdgcn_sched_barrier(0); }
-        if (nt == 3) { fb[cur ^ 1][mt] = *(const bf16x8*)(s + bbase + mt * 2048); __builtin_amdgcn_sched_barrier(0); }
+        if (nt == 1) { fa[cur ^ 1][mt] = *(const bf16x8*)(s + abase + mt * G4_FSTR); __builtin_amdgcn_sched_barrier(0); }
+        if (nt == 3) { fb[cur ^ 1][mt] = *(const bf16x8*)(s + bbase + mt * G4_FSTR); __builtin_amdgcn_sched_barrier(0); }
         if (nt == 5 && dma) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + mt * 4096), 16, dead ? GEMM_OOB : voA[mt], k0 * 2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + mt * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voA[mt], k0 * 2, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (nt == 7 && dma) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + mt * 4096), 16, dead ? GEMM_OOB : voB[mt], k0 * 2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + G4_BOFF + mt * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voB[mt], k0 * 2, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1440,7 +1465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     const char* s = smem + ph[0];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * 2048); fb[0][i] = *(const bf16x8*)(s + bbase + i * 2048); }
+    for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * G4_FSTR); fb[0][i] = *(const bf16x8*)(s + bbase + i * G4_FSTR); }
   }
   for (int t = 0; t < nkt; ++t) {
     kstep(0, t, 1, false, 0);                              // k-step 0; reads this tile's k-step-1 operands
@@ -1471,22 +1496,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const __amdgpu_buffer_rsrc_t rsBz = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0, 0x00020000);
   auto dma_a = [&](auto k64_t, const int td, const int j) {
     const int k0 = td * 64;
-    char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
+    char* dst = smem + (td & 1) * G4_STAGE + wave * G4_PIECE;
     if constexpr (decltype(k64_t)::value) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsAz : rsA, LDS_PTR(dst + j * 4096), 16, voA[j], k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsAz : rsA, LDS_PTR(dst + j * (4 * G4_PIECE)), 16, voA[j], k0 * 2, 0, 0);
     } else {
       const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * 4096), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
     }
   };
   auto dma_b = [&](auto k64_t, const int td, const int j) {
     const int k0 = td * 64;
-    char* dst = smem + (td & 1) * G4_STAGE + wave * 1024;
+    char* dst = smem + (td & 1) * G4_STAGE + wave * G4_PIECE;
     if constexpr (decltype(k64_t)::value) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsBz : rsB, LDS_PTR(dst + 32768 + j * 4096), 16, voB[j], k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((k0 >= Kv || (G4_ABL & 16)) ? rsBz : rsB, LDS_PTR(dst + G4_BOFF + j * (4 * G4_PIECE)), 16, voB[j], k0 * 2, 0, 0);
     } else {
       const bool dead = (G4_ABL & 16) || (k0 + cchunk * 8 >= Kv);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + 32768 + j * 4096), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + G4_BOFF + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
     }
   };
 #define G4_MFMA(cur, idx) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(idx) >> 3][(idx) & 7]) : "v"(fb[cur][(idx) & 7]), "v"(fa[cur][(idx) >> 3]))
@@ -1501,7 +1526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     const char* s = smem + ph[0];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * 2048); fb[0][i] = *(const bf16x8*)(s + bbase + i * 2048); }
+    for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * G4_FSTR); fb[0][i] = *(const bf16x8*)(s + bbase + i * G4_FSTR); }
   }
   auto run_loop = [&](auto k64_t) {
   for (int t = 0; t < nkt; ++t) {
@@ -1514,8 +1539,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 0
       G4_MFMA(0, idx);
-      if (idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * 2048); G4_SB(); }
-      if (idx >= 16 && idx < 32 && !(idx & 1)) { fb[1][(idx - 16) >> 1] = *(const bf16x8*)(sx + bbase + ((idx - 16) >> 1) * 2048); G4_SB(); }
+      if (idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * G4_FSTR); G4_SB(); }
+      if (idx >= 16 && idx < 32 && !(idx & 1)) { fb[1][(idx - 16) >> 1] = *(const bf16x8*)(sx + bbase + ((idx - 16) >> 1) * G4_FSTR); G4_SB(); }
       if (idx == 38) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G4_BARRIER(); G4_SB(); }
       if (idx >= 39 && idx <= 59 && (idx - 39) % 5 == 0) { piece((idx - 39) / 5); G4_SB(); }                       // pieces 0-4
     }
@@ -1528,8 +1553,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (idx >= 25 && idx <= 55 && (idx - 25) % 6 == 0) { piece(10 + (idx - 25) / 6); G4_SB(); }                  // pieces 10-15
       if (idx >= 23 && idx <= 46 && (idx - 23) % 3 != 2) {
         const int f = ((idx - 23) / 3) * 2 + (idx - 23) % 3;
-        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * 2048);
-        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * 2048);
+        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * G4_FSTR);
+        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * G4_FSTR);
         G4_SB();
       }
     }
@@ -1538,13 +1563,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int idx = 0; idx < 64; ++idx) {                             // ---- k-step 0
       G4_MFMA(0, idx);
       // A fragments of k-step 1: behind MFMAs 0, 2, ..., 14
-      if (!(G4_ABL & 4) && idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * 2048); G4_SB(); }
+      if (!(G4_ABL & 4) && idx < 16 && !(idx & 1)) { fa[1][idx >> 1] = *(const bf16x8*)(sx + abase + (idx >> 1) * G4_FSTR); G4_SB(); }
       if (idx == 21) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 1
       // A(t+2): behind MFMAs 22, 27, ..., 57 (the four waves share ONE address unit, 16 cycles per 1 KiB piece: pieces issued every 3
       // MFMAs by all four waves oversubscribe it and the in-order waves stall behind their own VMEM issue);  B fragments of k-step 1:
       // behind 24, 27, ..., 45
       if (!(G4_ABL & 2) && idx >= 22 && idx <= 57 && (idx - 22) % 5 == 0) { dma_a(k64_t, t + 2, (idx - 22) / 5); G4_SB(); }
-      if (!(G4_ABL & 4) && idx >= 24 && idx <= 45 && (idx - 24) % 3 == 0) { fb[1][(idx - 24) / 3] = *(const bf16x8*)(sx + bbase + ((idx - 24) / 3) * 2048); G4_SB(); }
+      if (!(G4_ABL & 4) && idx >= 24 && idx <= 45 && (idx - 24) % 3 == 0) { fb[1][(idx - 24) / 3] = *(const bf16x8*)(sx + bbase + ((idx - 24) / 3) * G4_FSTR); G4_SB(); }
       if (idx == 54) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(G4_ABL & 1)) G4_BARRIER(); G4_SB(); }   // barrier 2
       if (!(G4_ABL & 2) && idx == 62) { dma_b(k64_t, t + 2, 0); G4_SB(); }                                                       // B(t+2) piece 0
     }
@@ -1560,8 +1585,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // k-step-0 fragments of tile t+1: two behind every three MFMAs, the last one 12 MFMAs ahead of the loop end
       if (!(G4_ABL & 4) && idx >= 23 && idx <= 46 && (idx - 23) % 3 != 2) {
         const int f = ((idx - 23) / 3) * 2 + (idx - 23) % 3;         // 0..15: A fragments 0-7, then B fragments 0-7
-        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * 2048);
-        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * 2048);
+        if (f < 8) fa[0][f] = *(const bf16x8*)(sy + abase + f * G4_FSTR);
+        else fb[0][f - 8] = *(const bf16x8*)(sy + bbase + (f - 8) * G4_FSTR);
         G4_SB();
       }
     }
@@ -1569,7 +1594,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     G4_SB();
   }
   };
+#if G4_ASM
+  // K % 64 == 0 (every launch of the step on this kernel): the loop as ONE hand-placed asm statement (gemm4_loop_asm.h, written
+  // by tools/gen_gemm4_loop.py); the hipcc-scheduled loop above stays for ragged reduction lengths and as the A/B arm (G4_ASM=0)
+  if ((Kv & 63) == 0) {
+    if (nkt > 0) {
+      const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+      uint32_t g4_ra1 = lds0 + ph[1] + abase, g4_rb1 = lds0 + ph[1] + bbase;                         // tile 0: stage 0, k-half 1
+      uint32_t g4_ra0 = lds0 + G4_STAGE + ph[0] + abase, g4_rb0 = lds0 + G4_STAGE + ph[0] + bbase;   // tile 1: stage 1, k-half 0
+      uint32_t g4_nk = __builtin_amdgcn_readfirstlane(nkt), g4_koff = 256u;
+      const uint32_t g4_klim = __builtin_amdgcn_readfirstlane(Kv * 2);
+      uint32_t g4_dma = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+      const unsigned long long pa = (unsigned long long)Ab, pb = (unsigned long long)Bb;
+      const uint32_t g4_dA[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffffu)),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)bytesA), 0x00020000u};
+      const uint32_t g4_dB[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pb >> 32) & 0xffffu)),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)bytesB), 0x00020000u};
+      G4_ASM_LOOP();
+    }
+  } else run_loop(std::false_type{});
+#else
   if ((Kv & 63) == 0) run_loop(std::true_type{}); else run_loop(std::false_type{});
+#endif
 #undef G4_MFMA
 #undef G4_SB
 #endif

@@ -611,8 +611,9 @@ int lmod_add_bf16(const void* a, const void* b, void* out, long long n, hipStrea
 
 int lmod_gather_rows(const void* srcA, const void* srcB, const int* idx, void* out, long long rows, int H,
                      hipStream_t stream) {
-  if (!idx || !out || rows < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
-  if (rows == 0) return LMOD_OK;
+  if (rows < 0 || H <= 0 || (H & 7)) return LMOD_EINVAL;
+  if (rows == 0) return LMOD_OK;                  // an empty gather has no pointers to check (an expert-parallel rank with no live rows)
+  if (!idx || !out) return LMOD_EINVAL;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (H >> 3))), dim3(256), 0, stream, (const bf16_t*)srcA,
                      (const bf16_t*)srcB, idx, (bf16_t*)out, rows, H);
   return lmod_launch_status();

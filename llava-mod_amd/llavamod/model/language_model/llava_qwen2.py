@@ -279,7 +279,10 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         gen = None
         if do_sample:
             gen = torch.Generator(device=logits.device)
-            gen.manual_seed(int(seed) if seed is not None else torch.seed() & 0x7FFFFFFF)
+            # no `seed`: DRAW one from the global generator (deterministic under torch.manual_seed) — never reseed it: torch.seed()
+            # would change torch.initial_seed(), from which the MoE layers derive their gating-noise stream, so a sampling
+            # generate() between two training steps would silently fork the training run
+            gen.manual_seed(int(seed) if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         out = []
         for step in range(max_new_tokens):
             nxt = self._sample(logits, temperature, top_k, top_p, gen) if do_sample else K.row_argmax(logits)
@@ -295,11 +298,10 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         return torch.stack(out, 1)
 
     # ---- checkpoints in the reference's layout -----------------------------------------------------------------------
-    def save_pretrained(self, save_directory, max_shard_bytes=5 << 30):
-        """config.json + HF-layout safetensors shards (+ mm_projector.bin), loadable by `from_pretrained`."""
+    def save_config(self, save_directory):
+        """`config.json` alone (the reference: `model.config.save_pretrained(output_dir)`, align_trainer.py:631)."""
         import json
         import os
-        from ...checkpoint import save_checkpoint
         os.makedirs(save_directory, exist_ok=True)
         cfg = {}
         for k, v in vars(self.config).items():
@@ -309,10 +311,15 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
                 cfg[k] = v
         cfg["model_type"] = getattr(self.config, "model_type", None)
         cfg["architectures"] = [type(self).__name__]
-        tmp = os.path.join(save_directory, "config.json.tmp")
+        tmp = os.path.join(save_directory, f"config.json.tmp{os.getpid()}")
         with open(tmp, "w") as f:                              # temp file + rename: a crash never leaves half a config
             json.dump(cfg, f, indent=1)
         os.replace(tmp, os.path.join(save_directory, "config.json"))
+
+    def save_pretrained(self, save_directory, max_shard_bytes=5 << 30):
+        """config.json + HF-layout safetensors shards (+ mm_projector.bin), loadable by `from_pretrained`."""
+        from ...checkpoint import save_checkpoint
+        self.save_config(save_directory)
         return save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes)
 
     def save_mm_adapter(self, output_dir, keys_to_match=("mm_projector",)):
@@ -326,8 +333,9 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         if not sd:
             raise ValueError(f"no parameter matches {keys_to_match}")
         path = os.path.join(output_dir, "mm_projector.bin")
-        torch.save(sd, path + ".tmp")
-        os.replace(path + ".tmp", path)
+        tmp = f"{path}.tmp{os.getpid()}"                      # per-process temp name: two writers never share a half-written file
+        torch.save(sd, tmp)
+        os.replace(tmp, path)
         return path
 
     @classmethod

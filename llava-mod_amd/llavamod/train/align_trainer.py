@@ -163,13 +163,26 @@ class AlignTrainer:
         del self._stored_metrics[train_eval]
         return logs
 
-    def _save_checkpoint(self, model, output_dir, trial=None, metrics=None):
-        """train/align_trainer.py:616-636: with `tune_mm_mlp_adapter` only the adapter is saved (config + `mm_projector.bin`
-        holding the `mm_projector` parameters under their full names); otherwise the full HF-layout checkpoint."""
+    def _save_checkpoint(self, model, trial=None, metrics=None, output_dir=None):
+        """train/align_trainer.py:616-636, same positional signature `(model, trial, metrics)`.  The folder is the reference's
+        `<args.output_dir>/checkpoint-<global_step>` unless `output_dir` names one.  With `tune_mm_mlp_adapter` only the adapter
+        is saved — `config.json` (the reference calls `config.save_pretrained`) + `mm_projector.bin` holding the `mm_projector`
+        parameters under their full names — and only by the rank whose `args.local_rank` is 0 or -1, like the reference (every
+        rank holds the same replicated adapter; concurrent writers of one file would race).  Otherwise the full HF-layout
+        checkpoint, rank 0 only."""
+        import os
+        if output_dir is None:
+            step = getattr(getattr(self, "state", None), "global_step", 0)
+            output_dir = os.path.join(getattr(self.args, "output_dir", "."), f"checkpoint-{step}")
+        local_rank = getattr(self.args, "local_rank", -1)
+        if local_rank not in (0, -1, None):
+            return None
         if getattr(self.args, "tune_mm_mlp_adapter", False):
             keys = ["mm_projector", "vision_resampler"]
             if getattr(self.args, "use_im_start_end", False):
                 keys.extend(["embed_tokens", "embed_in"])
+            os.makedirs(output_dir, exist_ok=True)
+            model.save_config(output_dir)
             return model.save_mm_adapter(output_dir, keys_to_match=tuple(keys))
         return model.save_pretrained(output_dir)
 

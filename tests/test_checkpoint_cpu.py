@@ -148,6 +148,32 @@ def test_adapter_only_save_matches_the_reference_file(tmp_path):
     assert all(p.requires_grad for p in model.get_model().mm_projector.parameters())
 
 
+def test_trainer_save_checkpoint_reference_signature_rank_gate_and_config(tmp_path):
+    """`AlignTrainer._save_checkpoint(model, trial, metrics)` (train/align_trainer.py:616-636): the folder is
+    `<output_dir>/checkpoint-<global_step>`, the adapter-only form writes `config.json` + `mm_projector.bin`, and only the rank
+    with local_rank 0 / -1 writes."""
+    from types import SimpleNamespace
+    from llavamod.model import LlavaQwen2ForCausalLM
+    from llavamod.train.align_trainer import AlignTrainer
+    model = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, device="cpu")
+    tr = AlignTrainer.__new__(AlignTrainer)
+    tr.state = SimpleNamespace(global_step=7)
+    tr.args = SimpleNamespace(tune_mm_mlp_adapter=True, output_dir=str(tmp_path), local_rank=1)
+    assert tr._save_checkpoint(model, None) is None and not os.path.exists(tmp_path / "checkpoint-7")
+    tr.args.local_rank = 0
+    path = tr._save_checkpoint(model, None, metrics={"loss": 1.0})
+    assert path == str(tmp_path / "checkpoint-7" / "mm_projector.bin")
+    assert sorted(os.listdir(tmp_path / "checkpoint-7")) == ["config.json", "mm_projector.bin"]
+    import json
+    cfg = json.load(open(tmp_path / "checkpoint-7" / "config.json"))
+    assert cfg["architectures"] == ["LlavaQwen2ForCausalLM"] and cfg["hidden_size"] == model.config.hidden_size
+    tr.args = SimpleNamespace(tune_mm_mlp_adapter=False, output_dir=str(tmp_path), local_rank=-1)
+    tr._save_checkpoint(model, None, output_dir=str(tmp_path / "full"))
+    again = LlavaQwen2ForCausalLM.from_pretrained(str(tmp_path / "full"), device="cpu")
+    a, b = model.state_dict(), again.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
 def test_named_tower_never_random_initialises(tmp_path):
     """A tower given by NAME loads from a local directory or from the main checkpoint's own tensors — otherwise it raises
     (VERDICT r02 missing #2: `CLIPVisionModel.from_pretrained(self.image_tower_name)`, clip_encoder.py:24-33)."""

@@ -96,38 +96,46 @@ def _worker(rank, world, port, q):
         return out
     K.gather_rows = gather_rows
     El, C, H = 2, 5, 4
-    g = torch.Generator().manual_seed(100 + rank)
-    used = torch.randint(0, C + 1, (world, El), generator=g, dtype=torch.int32)      # my live slots per (dest rank, expert)
-    used[rank, 0] = 0                                                                # an empty slab
-    slab = torch.randn(world * El * C, H, generator=g)
-    for r in range(world):
-        for le in range(El):
-            base = (r * El + le) * C
-            slab[base + int(used[r, le]):base + C] = 0                               # empty slots are zero rows
-    rr = torch.empty_like(used)
-    dist.all_to_all_single(rr, used.contiguous(), group=grp)
-    full_in = slab.clone().requires_grad_(True)
-    full = ops.AllToAll.apply(full_in.view(world, El * C, H), grp).reshape(world * El * C, H)
-    pl = ops.ep_live_row_plan(used.numpy(), rr.numpy(), C, "cpu")
-    assert pl.in_splits == used.sum(1).tolist() and pl.out_splits == rr.sum(1).tolist()
-    live_in = slab.clone().requires_grad_(True)
-    packed = ops.RowGather.apply(live_in, pl.send_idx, pl.send_inv)
-    assert packed.shape[0] == int(used.sum())
-    recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, grp)
-    recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)
-    assert torch.equal(recv.detach(), full.detach())                                 # dead slots: zero rows in both
-    wgt = torch.randn(world * El * C, H, generator=torch.Generator().manual_seed(7 + rank))
-    (full * wgt).sum().backward()
-    (recv * wgt).sum().backward()
-    livemask = (pl.send_inv >= 0)
-    assert torch.equal(live_in.grad[livemask], full_in.grad[livemask]) and float(live_in.grad[~livemask].abs().max()) == 0.0
-    # and the way back: expert outputs of the live rows return to their slots
-    y = recv.detach() * 2.0 + 1.0
-    y_p = ops.RowGather.apply(y, pl.recv_inv, pl.recv_slab)
-    back_p = ops.AllToAllRows.apply(y_p, pl.out_splits, pl.in_splits, grp)
-    back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)
-    back_full = ops.AllToAll.apply(y.view(world, El * C, H), grp).reshape(world * El * C, H)
-    assert torch.equal(back[livemask], back_full[livemask]) and torch.equal(back[livemask], slab[livemask] * 2.0 + 1.0)
+
+    def live_case(starve):
+        g = torch.Generator().manual_seed(100 + rank)
+        used = torch.randint(0, C + 1, (world, El), generator=g, dtype=torch.int32)  # my live slots per (dest rank, expert)
+        used[rank, 0] = 0                                                            # an empty slab
+        if starve is not None:      # nobody routes anything to rank `starve`: its packed receive buffer has ZERO rows (ADVICE r03:
+            used[starve] = 0        # a collapsed router, ep == num_experts, or a tiny eval batch) and it sends its rows as usual
+        slab = torch.randn(world * El * C, H, generator=g)
+        for r in range(world):
+            for le in range(El):
+                base = (r * El + le) * C
+                slab[base + int(used[r, le]):base + C] = 0                               # empty slots are zero rows
+        rr = torch.empty_like(used)
+        dist.all_to_all_single(rr, used.contiguous(), group=grp)
+        full_in = slab.clone().requires_grad_(True)
+        full = ops.AllToAll.apply(full_in.view(world, El * C, H), grp).reshape(world * El * C, H)
+        pl = ops.ep_live_row_plan(used.numpy(), rr.numpy(), C, "cpu")
+        assert pl.in_splits == used.sum(1).tolist() and pl.out_splits == rr.sum(1).tolist()
+        live_in = slab.clone().requires_grad_(True)
+        packed = ops.RowGather.apply(live_in, pl.send_idx, pl.send_inv)
+        assert packed.shape[0] == int(used.sum())
+        recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, grp)
+        recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)
+        assert torch.equal(recv.detach(), full.detach())                                 # dead slots: zero rows in both
+        wgt = torch.randn(world * El * C, H, generator=torch.Generator().manual_seed(7 + rank))
+        (full * wgt).sum().backward()
+        (recv * wgt).sum().backward()
+        livemask = (pl.send_inv >= 0)
+        assert torch.equal(live_in.grad[livemask], full_in.grad[livemask]) and float(live_in.grad[~livemask].abs().max()) == 0.0
+        # and the way back: expert outputs of the live rows return to their slots
+        y = recv.detach() * 2.0 + 1.0
+        y_p = ops.RowGather.apply(y, pl.recv_inv, pl.recv_slab)
+        back_p = ops.AllToAllRows.apply(y_p, pl.out_splits, pl.in_splits, grp)
+        back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)
+        back_full = ops.AllToAll.apply(y.view(world, El * C, H), grp).reshape(world * El * C, H)
+        assert torch.equal(back[livemask], back_full[livemask]) and torch.equal(back[livemask], slab[livemask] * 2.0 + 1.0)
+        return int(rr.sum())
+    live_case(None)
+    got = live_case(1)
+    assert (got == 0) == (rank == 1)
     # rank-distinct synthetic shards (bench.py seeds batches with the rank)
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))

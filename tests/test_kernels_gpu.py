@@ -81,6 +81,30 @@ def test_gemm_big_tile_path_all_epilogues():
     assert torch.equal(got[:K_].float(), b.float().t()) and got[K_:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("K_", [64, 128, 192, 448, 2048])
+def test_gemm_big_tile_k64_hand_placed_loop(K_):
+    # K % 64 == 0 on the four-wave kernel = the K loop as one asm statement (gemm4_loop_asm.h).  1, 2, 3, 7 and 32 K tiles: the
+    # first cases end inside the prefetch distance (tiles past the end switch to a zero-record descriptor); ragged M / N edges;
+    # plain, bias + activation, the fused QKV + RoPE epilogue's plain cousin (bias only) and the fused SwiGLU forward share the loop
+    M, N = 4000, 2568
+    a, b, bias = rnd(M, K_, seed=80 + K_), rnd(N, K_, seed=81 + K_), rnd(N, seed=82)
+    ref = a.float() @ b.float().t()
+    close(K_gemm(a, b), ref, f"k64 gemm K={K_}")
+    pre = (ref + bias.float()).to(BF).float()
+    close(K_gemm(a, b, bias=bias, act=1), F.gelu(pre), f"k64 gemm+bias+gelu K={K_}")
+    assert torch.equal(K_gemm(a, b), K_gemm(a, b))
+    eye = torch.eye(M, K_, device=DEV, dtype=BF)
+    got = K_gemm(eye, b)
+    assert torch.equal(got[:K_].float(), b.float().t()) and got[K_:].abs().max().item() == 0
+    I = 1280
+    wgu = rnd(2 * I, K_, seed=83 + K_)
+    gu_ref = K.gemm_nt(a, wgu)
+    act, gu = K.gemm_swiglu(a, wgu, want_gu=True)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:]))
+    g, u = a.float() @ wgu[:I].float().t(), a.float() @ wgu[I:].float().t()
+    close(act, F.silu(g.to(BF).float()).to(BF).float() * u.to(BF).float(), f"k64 fused swiglu K={K_}")
+
+
 def test_gemm_bias_act_f32_accumulate():
     M, N, K_ = 200, 264, 320
     a, b, bias = rnd(M, K_, seed=3), rnd(N, K_, seed=4), rnd(N, seed=5)

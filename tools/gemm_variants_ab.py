@@ -12,6 +12,7 @@ ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--shapes", default="qkv")
 ap.add_argument("--only", default="")
+ap.add_argument("--vendor", action="store_true", help="add PyTorch-ROCm F.linear (hipBLASLt) as an arm: the yardstick on the same box, same process")
 ap.add_argument("--pads", default="0", help="comma list: extra elements on both operands' leading dimensions (L2 channel striding probe)")
 args = ap.parse_args()
 SHAPES = {"qkv": (32768, 12288, 4096), "sq8k": (8192, 8192, 8192), "sdown": (32768, 2048, 5504), "sqkv": (32768, 6144, 2048),
@@ -80,13 +81,21 @@ for sh0 in [f"{x}+{pd}" for x in args.shapes.split(",") for pd in args.pads.spli
         for _ in range(n):
             rc = f(a.data_ptr(), b.data_ptr(), o.data_ptr(), None, M, N, Kd, ld, ld, N, 1, 0, 0, 0, None, None, 0, 0, 0, s)
             assert rc == 0
+    if args.vendor and "vendor" not in fns:
+        fns["vendor"] = None
+    def run(f, n, _run=run):
+        if f is None:
+            for _ in range(n):
+                torch.nn.functional.linear(a[:, :Kd], b[:, :Kd])
+        else:
+            _run(f, n)
     ref = None
     for name, f in fns.items():             # warm up; results of every build against the current one (timing-only builds differ)
         o.zero_(); run(f, 3); torch.cuda.synchronize()
         if ref is None:
             ref = o.clone()
         else:
-            print(f"# {sh} {name}: max |out - current| = {(o.float() - ref.float()).abs().max().item():.4g}", flush=True)
+            if f is not None: print(f"# {sh} {name}: max |out - current| = {(o.float() - ref.float()).abs().max().item():.4g}", flush=True)
     for rnd in range(args.rounds):
         for name, f in fns.items():
             t0 = time.perf_counter(); run(f, 20); torch.cuda.synchronize()

@@ -18,7 +18,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 struct P { const uint16_t* A; const uint16_t* B; int M, N, K, tiles_m, tiles_n; uint32_t* sink; int waves; };
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int SWZ = 1>
 __global__ __launch_bounds__(512, 2) void stream_kernel(P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -34,7 +34,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(P p) {
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 256 * p.K * 2, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 256 * p.K * 2, 0x00020000);
   // piece j (0..3) of operand X for this wave: rows wave*32 + j*8 + (lane>>3), 16-byte chunk (lane&7)^(lane>>3)
-  const int cchunk = (lane & 7) ^ (lane >> 3);
+  // SWZ 1: the GEMM's XOR-swizzled source (16-byte chunks permuted inside each 128-byte row); 0: linear rows (round 4: does the
+  // permutation itself cost arrival rate?); 2: chunk pairs permuted only (32-byte granules stay contiguous)
+  const int cchunk = SWZ == 1 ? ((lane & 7) ^ (lane >> 3)) : SWZ == 2 ? ((lane & 7) ^ ((lane >> 3) & 6)) : (lane & 7);
   uint32_t vo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) vo[j] = (uint32_t)(((wave * 32 + j * 8 + (lane >> 3)) * p.K + cchunk * 8) * 2);
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(P p) {
   if (MODE == 1 && (accv[0] | accv[1] | accv[2] | accv[3]) == 0x12345u) p.sink[tid] = accv[0];
 }
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int SWZ = 1>
 static void run(const P& p, int nwg, const char* tag, double clk_ghz) {
-  hipFuncSetAttribute((const void*)stream_kernel<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)stream_kernel<MODE, DEPTH, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<MODE, DEPTH>), dim3(nwg), dim3(512), 131072, 0, p);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<MODE, DEPTH, SWZ>), dim3(nwg), dim3(512), 131072, 0, p);
   hipEventRecord(e0);
   const int n = 40;
-  for (int i = 0; i < n; ++i) hipLaunchKernelGGL((stream_kernel<MODE, DEPTH>), dim3(nwg), dim3(512), 131072, 0, p);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL((stream_kernel<MODE, DEPTH, SWZ>), dim3(nwg), dim3(512), 131072, 0, p);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= n;
   const double bytes = (double)nwg * (p.K / 64) * 65536.0 * p.waves / 8.0;
@@ -100,6 +102,10 @@ int main(int argc, char** argv) {
     run<0, 3>(p, nwg, "LDS-DMA, 3 K-steps in flight", ghz);
     run<0, 4>(p, nwg, "LDS-DMA, 4 K-steps in flight", ghz);
     run<1, 0>(p, nwg, "plain loads to VGPRs", ghz);
+    run<0, 2, 0>(p, nwg, "LDS-DMA, 2 K-steps, LINEAR source", ghz);
+    run<0, 3, 0>(p, nwg, "LDS-DMA, 3 K-steps, LINEAR source", ghz);
+    run<0, 3, 2>(p, nwg, "LDS-DMA, 3 K-steps, 32-B granules", ghz);
+    run<1, 0, 0>(p, nwg, "plain loads, LINEAR source", ghz);
   }
   return 0;
 }
