@@ -36,6 +36,7 @@ struct GemmP {
   float* ws; int* counters;            //   ws [splitk, M, N] partial tiles, counters [tiles] arrival semaphores (self-resetting)
   // MODE 5 (lmod_gemm_qkv_rope_bf16): rotary embedding of head-dim-128 heads in the epilogue
   const bf16_t* rope_cos; const bf16_t* rope_sin; const int* rope_pos; int rope_cols;
+  int ptotal;                          // persistent gemm4 launches: tiles in all (the grid is min(ptotal, CUs))
 };
 
 #define GEMM_OOB 0x80000000u
@@ -1327,76 +1328,127 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #endif
 #define G4_BOFF (32 * G4_PIECE)
 #define G4_FSTR (G4_PAD ? 128 : 2048)
-template <int MODE>
+struct G4Tile {      // one output tile: coordinates, operand windows, this lane's staging offsets
+  int id, bz, split, Mv, Kv, row0, col0, rowsA, rowsB, nkt;
+  const bf16_t* Ab; const bf16_t* Bb;
+  uint32_t bytesA, bytesB, voA[8], voB[8];
+};
+// PERSIST (round 4): one workgroup per CU walks the tile space (tile = blockIdx.x + i * gridDim.x, XCD-remapped as before).  After a
+// tile's K loop the NEXT tile's first two K tiles are put in flight (LDS-DMA) BEFORE this tile's epilogue, so the operand latency,
+// the workgroup turn-around and the index arithmetic hide under the epilogue's conversions and stores.  Plain launches only (no
+// m_valid / k_valid / split-K: the launcher decides); results are those of the one-tile-per-workgroup form, bit for bit.
+template <int MODE, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  // (not const: the persistent form re-launders them once per tile, see G4_LAUNDER)
+  int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wr = wave >> 1, wc = wave & 1;
 
   const int tpb = p.tiles_m * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  int bz = id / tpb, split = 0;
-  if (MODE == 0 && p.splitk > 1) { split = bz; bz = 0; id -= split * tpb; }
-  const int r = id - bz * tpb;
-  const int GROUP_M = G256_GROUP_M;
-  const int grp = r / (GROUP_M * p.tiles_n);
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int rr = r - grp * GROUP_M * p.tiles_n;
-  int tm = first_m + rr % gsz, tn = rr / gsz;
-  if (p.m_valid) {
-    if (p.batch <= GEMM_MAX_GROUPS) {
-      if (!grouped_tile<256, G256_GROUP_M>(p, bz, tm, tn)) return;
-    } else {
-      const int per_col = p.batch * p.tiles_m;
-      tn = id / per_col;
-      const int rem = id - tn * per_col;
-      bz = rem / p.tiles_m;
-      tm = rem - bz * p.tiles_m;
-    }
-  }
-  const int Mv = p.m_valid ? min(p.m_valid[bz], p.M) : p.M;
-  int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
-  const int row0 = tm * 256, col0 = tn * TN;
-  if (row0 >= Mv) return;
-  int kbeg = 0;
-  if (MODE == 0 && p.splitk > 1) {
-    kbeg = split * p.kchunk;
-    Kv = max(0, min(Kv - kbeg, p.kchunk));
-  }
-  const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda + kbeg;
-  const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb + kbeg;
-  const int rowsA = min(256, Mv - row0), rowsB = min(TN, p.N - col0);
-  const int Kv8 = (Kv + 7) & ~7;
-  const uint32_t bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
-  const uint32_t bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE == 1 ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)bytesA, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bytesB, 0x00020000);
-
   // staging: piece j of wave w fills LDS rows (j*4 + w)*8 + (lane>>3), physical chunk lane&7 (logical chunk ^ row&7)
-  const int cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
+  int cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
+  auto setup = [&](const int bid, const int nwg, G4Tile& T) -> bool {
+    // persistent launches carry no m_valid / k_valid (launcher): without the `PERSIST ? nullptr` below their loads — re-issued
+    // after the previous tile's stores, so not scalarisable — drag the whole tile arithmetic into VGPRs
+    const int* const mvp = PERSIST ? nullptr : p.m_valid;
+    const int* const kvp = PERSIST ? nullptr : p.k_valid;
+    int id = xcd_remap(bid, nwg);
+    int bz = id / tpb, split = 0;
+    if (MODE == 0 && p.splitk > 1) { split = bz; bz = 0; id -= split * tpb; }
+    const int r = id - bz * tpb;
+    const int GROUP_M = G256_GROUP_M;
+    const int grp = r / (GROUP_M * p.tiles_n);
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int rr = r - grp * GROUP_M * p.tiles_n;
+    int tm = first_m + rr % gsz, tn = rr / gsz;
+    if (mvp) {
+      if (p.batch <= GEMM_MAX_GROUPS) {
+        if (!grouped_tile<256, G256_GROUP_M>(p, bz, tm, tn)) return false;
+      } else {
+        const int per_col = p.batch * p.tiles_m;
+        tn = id / per_col;
+        const int rem = id - tn * per_col;
+        bz = rem / p.tiles_m;
+        tm = rem - bz * p.tiles_m;
+      }
+    }
+    const int Mv = mvp ? min(mvp[bz], p.M) : p.M;
+    int Kv = kvp ? min(kvp[bz], p.K) : p.K;
+    const int row0 = tm * 256, col0 = tn * TN;
+    if (row0 >= Mv) return false;
+    int kbeg = 0;
+    if (MODE == 0 && p.splitk > 1) {
+      kbeg = split * p.kchunk;
+      Kv = max(0, min(Kv - kbeg, p.kchunk));
+    }
+    T.id = id; T.bz = bz; T.split = split; T.Mv = Mv; T.Kv = Kv; T.row0 = row0; T.col0 = col0;
+    T.Ab = p.A + (long long)bz * p.sA + (long long)row0 * p.lda + kbeg;
+    T.Bb = p.B + (long long)bz * p.sB + (long long)col0 * p.ldb + kbeg;
+    const int rowsA = min(256, Mv - row0), rowsB = min(TN, p.N - col0);
+    T.rowsA = rowsA; T.rowsB = rowsB;
+    const int Kv8 = (Kv + 7) & ~7;
+    T.bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
+    T.bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE == 1 ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#if G4_PAD   // physical row p of a 128-row group holds logical row (p & 7) * 16 + (p >> 3): a lane's 8 fragments sit 128 bytes apart
+      const int lrp = (j * 4 + wave) * 8 + (lane >> 3), p128 = lrp & 127;
+      const int lr = (lrp & ~127) + (p128 & 7) * 16 + (p128 >> 3);
+#else
+      const int lr = (j * 4 + wave) * 8 + (lane >> 3);                      // LDS row 0..255
+#endif
+      T.voA[j] = (lr < rowsA) ? (uint32_t)((lr * p.lda + cchunk * 8) * 2) : GEMM_OOB;
+      const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
+      if (MODE != 1) {
+        const int nloc = grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);          // permuted tile column
+        T.voB[j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+      } else {       // groups 2wc / 2wc+1 = gate / up rows of output columns wc*64 .. +63
+        const int nloc = (grp64 >> 1) * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);
+        T.voB[j] = (nloc < rowsB) ? (uint32_t)((((long long)(grp64 & 1) * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
+      }
+    }
+    T.nkt = (Kv + 63) >> 6;
+    return true;
+  };
+  // descriptor of an operand window, from wave-uniform words the compiler can SEE are uniform (inside the tile loop it would
+  // otherwise wrap every LDS-DMA in a waterfall loop: guide T20)
+  auto rsrc_of = [&](const bf16_t* base, const uint32_t bytes) {
+    const unsigned long long q = (unsigned long long)base;
+    const unsigned long long qu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)qu, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  auto stage_tiles01 = [&](const G4Tile& T) {              // the first two K tiles of a tile (32 pieces per wave) -> both LDS stages
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(T.Ab, T.bytesA), rb = rsrc_of(T.Bb, T.bytesB);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k0 = t * 64;
+        char* dst = smem + t * G4_STAGE + wave * G4_PIECE;
+        const bool dead = (k0 + cchunk * 8 >= T.Kv);          // tiles past the end are fully out of bounds: zero fill, no traffic
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : T.voA[j], k0 * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(dst + G4_BOFF + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : T.voB[j], k0 * 2, 0, 0);
+      }
+  };
+  G4Tile T;
+  int pbid = blockIdx.x;
+  const int ptotal = PERSIST ? p.ptotal : (int)gridDim.x;
+  if (!setup(pbid, ptotal, T)) return;                     // (persistent launches carry no m_valid: every tile id is live)
+  stage_tiles01(T);
+  for (;;) {                                               // ---- one output tile per pass (exactly one pass unless PERSIST)
+  const int id = T.id, bz = T.bz, split = T.split, Mv = T.Mv, Kv = T.Kv, row0 = T.row0, col0 = T.col0, nkt = T.nkt;
+  const bf16_t* Ab = T.Ab; const bf16_t* Bb = T.Bb;
+  const uint32_t bytesA = T.bytesA, bytesB = T.bytesB;
   uint32_t voA[8], voB[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#if G4_PAD   // physical row p of a 128-row group holds logical row (p & 7) * 16 + (p >> 3): a lane's 8 fragments sit 128 bytes apart
-    const int lrp = (j * 4 + wave) * 8 + (lane >> 3), p128 = lrp & 127;
-    const int lr = (lrp & ~127) + (p128 & 7) * 16 + (p128 >> 3);
-#else
-    const int lr = (j * 4 + wave) * 8 + (lane >> 3);                      // LDS row 0..255
-#endif
-    voA[j] = (lr < rowsA) ? (uint32_t)((lr * p.lda + cchunk * 8) * 2) : GEMM_OOB;
-    const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
-    if (MODE != 1) {
-      const int nloc = grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);          // permuted tile column
-      voB[j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
-    } else {       // groups 2wc / 2wc+1 = gate / up rows of output columns wc*64 .. +63
-      const int nloc = (grp64 >> 1) * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);
-      voB[j] = (nloc < rowsB) ? (uint32_t)((((long long)(grp64 & 1) * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
-    }
-  }
-  const int nkt = (Kv + 63) >> 6;
+  for (int j = 0; j < 8; ++j) { voA[j] = T.voA[j]; voB[j] = T.voB[j]; }
+  __amdgpu_buffer_rsrc_t rsA = rsrc_of(Ab, bytesA);
+  __amdgpu_buffer_rsrc_t rsB = rsrc_of(Bb, bytesB);
+  (void)id; (void)split;
 
   f32x4 acc[8][8];
 #pragma unroll
@@ -1422,13 +1474,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define G4_ABL 0                    // timing ablations of the deep schedule (WRONG RESULTS): 1 no barriers, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no vmcnt wait, 16 every LDS-DMA out of range (no traffic)
 #endif
 #define G4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-  auto stage_piece = [&](int t, int j) {                   // tiles past the end are fully out of bounds: zero fill, no traffic
-    const int k0 = t * 64;
-    char* dst = smem + (t & 1) * G4_STAGE + wave * G4_PIECE;
-    const bool dead = (k0 + cchunk * 8 >= Kv);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voA[j], k0 * 2, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + G4_BOFF + j * (4 * G4_PIECE)), 16, dead ? GEMM_OOB : voB[j], k0 * 2, 0, 0);
-  };
 #if !G4_DEEP
   // one k-step: 64 MFMAs on (fa[cur], fb[cur]); in their shadow the fragments of the next k-step (stage ts, k-half kn) are
   // read into (fa[cur^1], fb[cur^1]) and, if DMA, the 16 LDS-DMA pieces of tile td are issued
@@ -1456,11 +1501,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
 
-#pragma unroll
-  for (int j = 0; j < 8; ++j) stage_piece(0, j);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) stage_piece(1, j);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // tile 0 landed (tile 1's 16 pieces may still fly)
+  // the first two K tiles were put in flight by stage_tiles01 (before the loop, or before the previous tile's epilogue)
+  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // loads and the previous tile's stores share the counter and retire out of order: no counted wait here
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed (tile 1's 16 pieces may still fly)
   G4_BARRIER();
   {
     const char* s = smem + ph[0];
@@ -1517,11 +1560,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define G4_MFMA(cur, idx) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(idx) >> 3][(idx) & 7]) : "v"(fb[cur][(idx) & 7]), "v"(fa[cur][(idx) >> 3]))
 #define G4_SB() __builtin_amdgcn_sched_barrier(0)
 
-#pragma unroll
-  for (int j = 0; j < 8; ++j) stage_piece(0, j);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) stage_piece(1, j);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // tile 0 landed (tile 1's 16 pieces may still fly)
+  // the first two K tiles were put in flight by stage_tiles01 (before the loop, or before the previous tile's epilogue)
+  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // loads and the previous tile's stores share the counter and retire out of order: no counted wait here
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed (tile 1's 16 pieces may still fly)
   G4_BARRIER();
   {
     const char* s = smem + ph[0];
@@ -1621,9 +1662,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   // the asm MFMAs are invisible to the hazard recognizer: let the last accumulator writes retire before reading them
   asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+
+  // PERSIST: everything below is lane / wave arithmetic that does not change from tile to tile, and hipcc hoists all of it out of
+  // the tile loop — i.e. ACROSS the K loop, where 404 of the 512 registers are taken: ~100 spilled VGPRs, reloaded through scratch
+  // behind the LDS-DMA queue (measured: -6 ... -12 %).  Laundering the lane / wave ids here makes their derived values new per tile.
+  if constexpr (PERSIST) {
+    asm volatile("" : "+v"(tid), "+s"(wave));
+    lane = tid & 63; li = lane & 15; g = lane >> 4;
+    cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
+    wr = wave >> 1; wc = wave & 1;
+  }
+
+  // PERSIST: the next tile's first two K tiles go in flight now, under this tile's epilogue.  The barrier: every wave has drained
+  // its LDS-DMA (the vmcnt(0) above, tiles past the end included) and finished its fragment reads, so both stages are free.
+  G4Tile Nx;
+  bool more = false;
+  if constexpr (PERSIST) {
+    pbid += (int)gridDim.x;
+    more = pbid < ptotal;
+    if (more) {
+      setup(pbid, ptotal, Nx);
+      G4_BARRIER();
+      stage_tiles01(Nx);
+    }
+  }
 #undef G4_BARRIER
 
-  // ---------------------------------------------------------------- epilogue
+  // ---------------------------------------------------------------- epilogue (a lambda: `return` = this tile is done)
+  auto epilogue = [&]() {
   if constexpr (MODE == 1) {      // lane: 16 gate columns (acc[mt][0..3]) and the same 16 up columns (acc[mt][4..7])
     const int cs = col0 + wc * 64 + g * 16;
     bf16_t* Cact = (bf16_t*)p.C + (long long)bz * p.sC;
@@ -2028,6 +2094,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (tid == 0) __hip_atomic_store(p.counters + id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  };
+  epilogue();
+  if (!PERSIST || !more) return;
+  T = Nx;
+  }                                                        // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2104,6 +2175,34 @@ static void launch_256x(const GemmP& p, long long nwg, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_256_kernel<MODE, false>), dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   }
 }
+// Persistent form of the 4-wave kernel (one workgroup per CU walks the tiles, the next tile's operands in flight under the epilogue):
+// plain launches with more tiles than CUs.  LMOD_GEMM_PERSIST=0 / 1 overrides the build's default (A/B runs).
+#ifndef G4_PERSIST_DEFAULT
+#define G4_PERSIST_DEFAULT 1
+#endif
+static int gemm_cus() {
+  static int n = 0;
+  if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; if (n <= 0) n = 256; }
+  return n;
+}
+static bool gemm_persist(const GemmP& p, long long nwg) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("LMOD_GEMM_PERSIST"); on = e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT; }
+  return on && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus();
+}
+template <int MODE>
+static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
+  static bool a = false, ap = false;
+  if (gemm_persist(p0, nwg)) {
+    GemmP p = p0;
+    p.ptotal = (int)nwg;
+    allow_lds(gemm4_kernel<MODE, true>, 2 * G4_STAGE, ap);
+    hipLaunchKernelGGL((gemm4_kernel<MODE, true>), dim3((unsigned)gemm_cus()), dim3(256), 2 * G4_STAGE, stream, p);
+  } else {
+    allow_lds(gemm4_kernel<MODE, false>, 2 * G4_STAGE, a);
+    hipLaunchKernelGGL((gemm4_kernel<MODE, false>), dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p0);
+  }
+}
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a44 = false, a46 = false, a47 = false;
@@ -2112,15 +2211,16 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   // one at K >= 4096 and level or slightly behind at K 2048, depending on N (profiles/r03_vendor_ab.md; in the step: -0.5 % / -0.7 % of
   // the plain / fused-SwiGLU kernel time): the plain bf16 store and the fused SwiGLU forward take it by default; split-K, k_valid
   // batches (their XCD balancing lives in the 8-wave kernel) and the rare option mixes stay on 8 waves
-  if (w == 4 || ((w == 0 || w == 44) && MODE == 1)) {
+  if ((w == 0 || w == 44) && MODE == 1) {
+    launch_4<1>(p, nwg, stream);
+  } else if (w == 4) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3) {     // (in-step: 1177 us per launch against 1124 us for
     allow_lds(gemm4_kernel<4>, 2 * G4_STAGE, a44);                                       //  the 8-wave kernel's two-batch epilogue: not routed)
     hipLaunchKernelGGL(gemm4_kernel<4>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if ((w == 0 || w == 44) && MODE == 0 && p.splitk <= 1 && !p.k_valid && !p.out_f32 && !p.accumulate && p.act != 3) {
-    allow_lds(gemm4_kernel<7>, 2 * G4_STAGE, a47);
-    hipLaunchKernelGGL(gemm4_kernel<7>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+    launch_4<7>(p, nwg, stream);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) {   // (not routed: the 8-wave MODE 6 has the two-batch read-modify-write)
     allow_lds(gemm4_kernel<6>, 2 * G4_STAGE, a46);
     hipLaunchKernelGGL(gemm4_kernel<6>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);

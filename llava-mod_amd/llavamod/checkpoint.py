@@ -142,8 +142,9 @@ def save_optimizer(opt, out_dir):
     os.makedirs(out_dir, exist_ok=True)
     st = opt.state_dict()
     path = os.path.join(out_dir, f"optimizer_rank{st['rank']}_of{st['world']}.pt")
-    torch.save(st, path + ".tmp")
-    os.replace(path + ".tmp", path)
+    tmp = f"{path}.tmp{os.getpid()}"
+    torch.save(st, tmp)
+    os.replace(tmp, path)
     return path
 
 
@@ -155,5 +156,6 @@ def load_optimizer(opt, in_dir):
     path = os.path.join(in_dir, f"optimizer_rank{rank}_of{world}.pt")
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path}: no optimizer state for rank {rank} of {world}")
-    opt.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    # tensors, numbers, strings, lists and dicts only (HipAdamW.state_dict): no pickled code is ever executed on resume
+    opt.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
     return path

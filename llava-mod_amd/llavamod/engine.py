@@ -388,6 +388,8 @@ class HipAdamW:
 
     def resync_master(self):
         """fp32 masters <- current weights (construction; after a checkpoint was loaded into the model)."""
+        self._masters_from_file = False
+        self._weights_epoch = getattr(self.gb.model, "_weights_epoch", 0)
         for kind, obj, lo, hi, soff, _, off in self.items:
             src = self._target(kind, obj).reshape(-1)[lo - off:hi - off]
             self.master[soff:soff + hi - lo].copy_(src.float())
@@ -434,6 +436,12 @@ class HipAdamW:
         if ep != self._weights_epoch:
             # a checkpoint was loaded into the model after this optimizer took its fp32 masters (checkpoint.load_checkpoint
             # bumps the epoch): stepping from the stale masters would overwrite the just-loaded weights
+            if getattr(self, "_masters_from_file", False):
+                # ... but THESE masters came from an optimizer file: re-deriving them from the bf16 weights would silently
+                # turn an exact resume into an inexact one.  The order is weights first, optimizer second.
+                raise RuntimeError("model weights were loaded AFTER load_state_dict() restored the fp32 masters: load the model "
+                                   "checkpoint first and the optimizer state second, or call resync_master() to accept "
+                                   "bf16-rounded masters")
             self.resync_master()
             self._weights_epoch = ep
         self.step_count += 1
@@ -487,30 +495,47 @@ class HipAdamW:
 
     # ---- exact resume ------------------------------------------------------------------------------------------------
     def _layout(self):
-        return [(kind, lo, hi, soff) for kind, _, lo, hi, soff, _, _ in self.items]
+        return [[kind, int(lo), int(hi), int(soff)] for kind, _, lo, hi, soff, _, _ in self.items]
+
+    def _moes(self):
+        return [m for m in self.gb.model.modules() if hasattr(m, "noise_state")]
 
     def state_dict(self):
         """This rank's optimizer state: fp32 master / m / v of the chunks it owns (all of them without ZeRO-2), the step
         count, the shard layout they belong to, and the MoE layers' gating-noise counters (so a resumed run continues the
-        noise stream).  With ZeRO-2 every rank saves its own (`checkpoint.save_optimizer` names the file by rank)."""
+        noise stream).  With ZeRO-2 every rank saves its own (`checkpoint.save_optimizer` names the file by rank).  Plain
+        tensors, ints, bools, strings, lists and dicts only: the file loads under `torch.load(weights_only=True)`."""
         self.sync()
-        moes = [m for m in self.gb.model.modules() if hasattr(m, "noise_state")]
         return {"step_count": self.step_count, "master": self.master.detach().cpu(), "m": self.m.detach().cpu(),
                 "v": self.v.detach().cpu(), "layout": self._layout(), "n_state": self.n_state,
                 "world": self.dp.world if self.dp is not None else 1, "rank": self.dp.rank if self.dp is not None else 0,
-                "zero2": bool(self.dp is not None and self.dp.zero2), "moe_noise": [m.noise_state() for m in moes]}
+                "zero2": bool(self.dp is not None and self.dp.zero2), "moe_noise": [m.noise_state() for m in self._moes()]}
 
     def load_state_dict(self, st):
-        if st["n_state"] != self.n_state or [tuple(x) for x in st["layout"]] != self._layout():
+        """Exact resume.  Everything that decides which numbers the file holds is compared BEFORE anything is copied: the span /
+        shard layout, the world size, this rank's index, the ZeRO-2 setting (without it the layout is identical on every rank,
+        so a file of another rank or another world size would load silently) and the MoE layer set (count and layer ids)."""
+        if st["n_state"] != self.n_state or [list(x) for x in st["layout"]] != self._layout():
             raise ValueError("optimizer state was saved under a different span / shard layout (world size, ZeRO-2 setting "
                              "or trainable set changed): it cannot be resumed exactly")
+        mine = {"world": self.dp.world if self.dp is not None else 1, "rank": self.dp.rank if self.dp is not None else 0,
+                "zero2": bool(self.dp is not None and self.dp.zero2)}
+        for k, v in mine.items():
+            if k in st and type(v)(st[k]) != v:
+                raise ValueError(f"optimizer state was saved with {k} = {st[k]}, this run has {k} = {v}: not the same shard")
+        moes, noise = self._moes(), list(st.get("moe_noise", []))
+        if len(noise) != len(moes):
+            raise ValueError(f"optimizer state holds gating-noise counters of {len(noise)} MoE layers, the model has {len(moes)}")
+        for m, ns in zip(moes, noise):
+            if int(ns.get("layer_id", m.noise_state()["layer_id"])) != int(m.noise_state()["layer_id"]):
+                raise ValueError(f"gating-noise counters of MoE layer {ns.get('layer_id')} offered to layer {m.noise_state()['layer_id']}")
         self.step_count = int(st["step_count"])
         for name in ("master", "m", "v"):
             getattr(self, name).copy_(st[name].to(getattr(self, name).device))
-        moes = [m for m in self.gb.model.modules() if hasattr(m, "noise_state")]
-        for m, ns in zip(moes, st.get("moe_noise", [])):
+        for m, ns in zip(moes, noise):
             m.load_noise_state(ns)
         self._weights_epoch = getattr(self.gb.model, "_weights_epoch", 0)    # masters come from the file, not the model
+        self._masters_from_file = True
 
     def sync(self):
         """Make the current stream wait for an overlapped step (before reading weights outside a forward)."""

@@ -53,3 +53,41 @@ def test_dpo_collator_contract():
     assert len(b["images"]) == 3
     assert set(b) == {"chosen_input_ids", "chosen_labels", "chosen_attention_mask", "rejected_input_ids", "rejected_labels",
                       "rejected_attention_mask", "images"}
+
+
+def _cases():
+    """The very instances `oracle/validate_vs_reference.py::collate_cases` fed to the IMPORTED reference collators (restated here:
+    tests may not import /root/reference, and the fixture holds the reference's OUTPUTS)."""
+    def inst(n, seed, n_img=1, bare=False):
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, 1000, (n,), generator=g)
+        lab = ids.clone(); lab[: n // 2] = -100
+        imgs = [torch.randn(3, 4, 4, generator=g) for _ in range(n_img)]
+        return dict(input_ids=ids, labels=lab, image=imgs[0] if bare else imgs)
+    sft = [inst(5, 1), inst(15, 2, n_img=2), inst(9, 3, bare=True), inst(12, 4)]
+    dpo = []
+    for k in range(3):
+        c, r = inst(6 + 4 * k, 10 + k, n_img=1 + (k == 1)), inst(20 - 5 * k, 20 + k)
+        dpo.append(dict(chosen_input_ids=c["input_ids"], chosen_labels=c["labels"], rejected_input_ids=r["input_ids"],
+                        rejected_labels=r["labels"], image=c["image"]))
+    return sft, dpo
+
+
+def test_collators_equal_the_imported_reference_collators():
+    """VERDICT r03 next #5a: `tests/golden/collate.safetensors` holds what the reference's own `DataCollatorForSupervisedDataset`
+    / `DataCollatorForDPODataset` (data/dataset.py:167-232, :434-505, imported by oracle/validate_vs_reference.py) returned for
+    these instances — every key, dtype, shape and value must agree, the flat image list included."""
+    from safetensors.torch import load_file
+    gold = load_file(os.path.join(ROOT, "tests", "golden", "collate.safetensors"))
+    sft, dpo = _cases()
+    for tag, b in (("sft", DataCollatorForSupervisedDataset(TOK)(sft)), ("dpo", DataCollatorForDPODataset(TOK)(dpo))):
+        keys = {k[len(tag) + 1:] for k in gold if k.startswith(tag + ".")}
+        assert set(b) == keys, (tag, set(b), keys)
+        for k, v in b.items():
+            ref = gold[f"{tag}.{k}"]
+            if k == "images":
+                assert len(v) == ref.shape[0] and all(torch.equal(a, r) for a, r in zip(v, ref))
+            elif k.endswith("attention_mask"):
+                assert v.dtype == torch.bool and torch.equal(v, ref.bool())
+            else:
+                assert v.dtype == ref.dtype and torch.equal(v, ref), (tag, k)

@@ -296,6 +296,7 @@ def _zero2_worker(rank, world, port, q, device="cpu"):
     a_gb.zero(); fake_grads(a_gb, 2)
     a_opt.dp.finish(); a_opt.step(grad_scale=1.0 / world, clear_grads=True)
     b_layer = build()
+    b_layer.mlp._layer_id = a_layer.mlp._layer_id                # a resumed PROCESS rebuilds the same layers in the same order
     with torch.no_grad():
         for n, p in b_layer.named_parameters():
             p.copy_(weights[n])
@@ -314,10 +315,41 @@ def _zero2_worker(rank, world, port, q, device="cpu"):
     c_gb = GradBuffer(c_layer)
     c_opt = HipAdamW(c_gb, dp=DataParallel(zero2=False).attach(c_gb))
     try:
-        c_opt.load_state_dict(torch.load(path, weights_only=False))
+        c_opt.load_state_dict(torch.load(path, weights_only=True))
         raise AssertionError("optimizer state of another shard layout was accepted")
     except ValueError:
         pass
+    # without ZeRO-2 the layout is the same on every rank, so world / rank / zero2 and the MoE layer set are
+    # compared too; and restoring masters BEFORE loading model weights is refused at the next step instead of silently
+    # re-deriving the masters from bf16 weights
+    st = c_opt.state_dict()
+    for key, bad in (("rank", (rank + 1) % world), ("world", world + 1), ("zero2", True)):
+        try:
+            c_opt.load_state_dict({**st, key: bad})
+            raise AssertionError(f"optimizer state with another {key} was accepted")
+        except ValueError:
+            pass
+    try:
+        c_opt.load_state_dict({**st, "moe_noise": st["moe_noise"] + [{"layer_id": 99, "calls": 0, "eval_calls": 0}]})
+        raise AssertionError("optimizer state of another MoE layer set was accepted")
+    except ValueError:
+        pass
+    if st["moe_noise"]:
+        try:
+            c_opt.load_state_dict({**st, "moe_noise": [{**st["moe_noise"][0], "layer_id": st["moe_noise"][0]["layer_id"] + 1}] + st["moe_noise"][1:]})
+            raise AssertionError("gating-noise counters of another layer id were accepted")
+        except ValueError:
+            pass
+    c_opt.load_state_dict(st)
+    c_layer._weights_epoch = getattr(c_layer, "_weights_epoch", 0) + 1        # what checkpoint.load_checkpoint does
+    try:
+        c_opt.step()
+        raise AssertionError("weights loaded after the optimizer state: the step went ahead from re-derived masters")
+    except RuntimeError:
+        pass
+    c_opt.resync_master()                                                      # the explicit way out
+    c_gb.zero()
+    c_opt.step()
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))

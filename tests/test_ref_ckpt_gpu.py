@@ -60,3 +60,32 @@ def test_reference_written_checkpoint_reproduces_reference_logits():
     print(f"reference-written checkpoint: logits max error {err:.3e}, bf16 floor {floor:.3e}, scale {ref[live].abs().max().item():.3e}")
     assert err <= 2.0 * floor, (err, floor)
     assert abs(float(out.loss) - float(exp["ref_loss"])) <= 1e-3 * abs(float(exp["ref_loss"]))
+
+
+def test_greedy_generate_reproduces_the_reference_continuation():
+    """VERDICT r03 next #5b / SURVEY §8 f4: `generate()` (prefill + KV-cache decode, `lmod_attn_decode`, row argmax) on the
+    reference-written checkpoint yields, token for token, the greedy continuation the IMPORTED reference model produced for the
+    same ragged prompt batch (oracle/validate_vs_reference.py::ref_greedy: the reference's own forward, cache-free, argmax at
+    every sample's last position).  The fixture's prompt was chosen for decision margins well above bf16 noise (smallest
+    top-1 / top-2 logit gap 0.029 against a bf16 logit error of ~0.007); the margins travel with the tokens."""
+    from safetensors.torch import load_file
+    from llavamod.model import LlavaQwen2ForCausalLM
+    exp = load_file(os.path.join(REF_CKPT, "expected.safetensors"))
+    model = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, attn_implementation="flash_attention_2",
+                                                  torch_dtype=torch.bfloat16, device="cuda")
+    want, margin = exp["gen_tokens"], exp["gen_margin"]
+    got = model.generate(input_ids=exp["gen_input_ids"], attention_mask=exp["gen_attention_mask"].bool(),
+                         images=exp["gen_images"].to("cuda").to(torch.bfloat16), max_new_tokens=want.shape[1]).cpu()
+    print(f"reference continuation {want.tolist()}, smallest decision margin {margin.min().item():.4f}; generate() -> {got.tolist()}")
+    assert got.shape == want.shape and got.dtype == torch.int64
+    assert torch.equal(got, want), (got.tolist(), want.tolist(), margin.tolist())
+    # same tokens one at a time through the HF-style cached forward (prepare_inputs_for_generation contract): the last-position
+    # logits of the uncached forward on prompt + continuation pick the same tokens
+    B = want.shape[0]
+    for i in range(B):
+        n = int(exp["gen_attention_mask"][i].sum())
+        ids = torch.cat([exp["gen_input_ids"][i, :n], want[i, :-1]])[None]
+        with torch.no_grad():
+            lg = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+                       images=exp["gen_images"][i:i + 1].to("cuda").to(torch.bfloat16)).logits
+        assert int(lg[0, -1].argmax()) == int(want[i, -1])

@@ -16,7 +16,7 @@ ap.add_argument("--vendor", action="store_true", help="add PyTorch-ROCm F.linear
 ap.add_argument("--pads", default="0", help="comma list: extra elements on both operands' leading dimensions (L2 channel striding probe)")
 args = ap.parse_args()
 SHAPES = {"qkv": (32768, 12288, 4096), "sq8k": (8192, 8192, 8192), "sdown": (32768, 2048, 5504), "sqkv": (32768, 6144, 2048),
-          "tdown": (32768, 4096, 11008), "sq4k": (4096, 4096, 4096)}
+          "tdown": (32768, 4096, 11008), "sq4k": (4096, 4096, 4096), "longk": (4096, 8192, 32768)}
 libs = {"current": os.path.join(ROOT, "llava-mod_amd", "llavamod", "_lib", "liblmod_hip.so")}
 for f in sorted(glob.glob(os.path.join(ROOT, "alt_libs", "*.so"))):
     libs[os.path.basename(f)[len("liblmod_"):-3]] = f

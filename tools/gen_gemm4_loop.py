@@ -26,6 +26,9 @@ import os
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", default="b2")
+ap.add_argument("--order", default="mn", help="mn: 8 consecutive MFMAs share the A-side fragment (src1), round 3's order; nm: they share the "
+                                          "B-side fragment (src0), the order of hipBLASLt's kernel")
+ap.add_argument("--split-barrier", type=int, default=0, help="1: the wait and its s_barrier one MFMA apart")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd", "csrc",
                                               "gemm4_loop_asm.h"))
 args = ap.parse_args()
@@ -37,7 +40,7 @@ sched = {i: [] for i in range(128)}      # MFMA index -> instructions behind it
 
 def mfma(i):
     ks, idx = i // 64, i % 64
-    mt, nt = idx >> 3, idx & 7
+    mt, nt = (idx >> 3, idx & 7) if args.order == "mn" else (idx & 7, idx >> 3)
     return f"v_mfma_f32_16x16x32_bf16 %[c{mt}_{nt}], %[b{ks}_{nt}], %[a{ks}_{mt}], %[c{mt}_{nt}]"
 
 
@@ -131,6 +134,17 @@ sched[127] += ["s_waitcnt lgkmcnt(0)", "s_cbranch_scc1 1b"]
 for i in range(128):
     assert len(sched[i]) <= 2 or any("s_barrier" in s for s in sched[i]), (i, sched[i])
 
+if args.split_barrier:
+    for i in [j for j in range(127) if "s_barrier" in sched[j]]:
+        if True:
+            k = sched[i].index("s_barrier")
+            sched[i] = sched[i][:k] + sched[i][k + 1:]        # (an M0 write behind it stays: one MFMA ahead of its LDS-DMA)
+            sched[i + 1] = ["s_barrier"] + sched[i + 1]
+    for i in range(128):                          # an M0 write must still sit exactly one MFMA ahead of its LDS-DMA
+        for ins in sched[i]:
+            if ins.startswith("buffer_load"):
+                assert any(x.startswith("s_add_u32 m0") for x in sched[i - 1]), i
+
 lines = [
     "s_mov_b32 s84, %[dA0]", "s_mov_b32 s85, %[dA1]", "s_mov_b32 s87, %[dA3]",
     "s_mov_b32 s88, %[dB0]", "s_mov_b32 s89, %[dB1]", "s_mov_b32 s91, %[dB3]",
@@ -173,7 +187,7 @@ n_dma = sum(1 for l in lines if "buffer_load" in l)
 n_rd = sum(1 for l in lines if "ds_read" in l)
 n_mf = sum(1 for l in lines if "v_mfma" in l)
 assert (n_dma, n_rd, n_mf) == (16, 32, 128), (n_dma, n_rd, n_mf)
-H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} — do not edit.  The K loop of gemm4_kernel as one inline-asm statement:",
+H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} — do not edit.  The K loop of gemm4_kernel as one inline-asm statement:",
      f"// per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l)} barriers; "
      f"{len(lines) - 11 - n_mf} other instructions.",
      "#pragma once",
