@@ -122,6 +122,102 @@ def executed_tflop_per_sample(S=2048, rows=513):
     return mimic_tflop(head_rows=rows) - (t_last + s_last) / 1e12
 
 
+def whole_step_object(units_per_s_per_gpu, stage):
+    """Whole-step MFMA utilisation.  PRIMARY: on the flops this implementation actually issues (lm_head and each model's last
+    dense layer only on the loss rows); beside it the figure on BASELINE.md's algorithmic ledger (VERDICT r03 next #4)."""
+    mult = 2.0 if stage == "dpo" else 1.0
+    ex, led = executed_tflop_per_sample() * mult, TFLOP_PER_SAMPLE_LEDGER * mult
+    return {"frac_executed": round(ex * units_per_s_per_gpu / PEAK_BF16_TFLOPS, 4), "achieved_executed": round(ex * units_per_s_per_gpu, 1),
+            "executed_tflop_per_unit": round(ex, 2),
+            "frac_ledger": round(led * units_per_s_per_gpu / PEAK_BF16_TFLOPS, 4), "achieved_ledger": round(led * units_per_s_per_gpu, 1),
+            "ledger_tflop_per_unit": round(led, 2),
+            "basis": "TFLOP per unit x units/s per GPU / 2500 TFLOP/s; executed = what the kernels run, ledger = BASELINE.md's algorithmic count"}
+
+
+def in_step_gemm_aggregate(step_fn, step_index):
+    """The dominant kernel INSIDE the step: one extra, untimed optimizer step with every `lmod_gemm_bf16_nt` launch bracketed by
+    events on its stream (`_hip.TRACE`); aggregate = sum of flops / sum of durations over the launches the library routes to
+    the plain bf16 256-tile kernel (gemm4_kernel<7>: bf16 store, no accumulate, no row / reduction masks, >= 160 tiles).  The
+    rocprofv3 figure of the same quantity is profiles/*_kernel_stats.md."""
+    from llavamod import _hip
+    _hip.TRACE = {"names": {"lmod_gemm_bf16_nt"}, "rows": []}
+    try:
+        step_fn(step_index)
+        torch.cuda.synchronize()
+        rows = _hip.TRACE["rows"]
+    finally:
+        _hip.TRACE = None
+    fl = ms = 0.0
+    n = 0
+    shapes = {}
+    for _, a, e0, e1 in rows:
+        M, N, Kd, batch, mv, kv, act, f32, accu = a[4], a[5], a[6], a[10], a[14], a[15], a[16], a[17], a[18]
+        if f32 or accu or mv or kv or act == 3 or M < 512 or N < 256:
+            continue
+        if ((M + 255) // 256) * ((N + 255) // 256) * batch < 160:
+            continue
+        t = e0.elapsed_time(e1)
+        fl += 2.0 * M * N * Kd * batch; ms += t; n += 1
+        k = f"{M}x{N}x{Kd}"
+        s = shapes.setdefault(k, [0, 0.0, 0.0])
+        s[0] += 1; s[1] += t; s[2] += 2.0 * M * N * Kd * batch
+    if not n:
+        return None
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
+    return {"kernel": "gemm4_kernel<7> launches of ONE optimizer step (events around every launch, teacher prefetch stream running beside)",
+            "launches": n, "ms": round(ms, 2), "achieved": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+            "by_shape": {k: {"launches": v[0], "ms": round(v[1], 2), "tflops": round(v[2] / v[1] / 1e9, 1)} for k, v in top}}
+
+
+def time_optimizer(gb, opt, grad_div, reps=3):
+    """SURVEY §8d: the optimizer step "reported separately" — global-norm clipping (sum of squares, coefficient) + the fused
+    AdamW over every trainable span of this rank, HIP events, after the timed region (zero gradients: same bytes, same kernels)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gb.zero()
+    opt.step(grad_scale=1.0 / grad_div, lr=0.0, clear_grads=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        opt.step(grad_scale=1.0 / grad_div, lr=0.0, clear_grads=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / reps, 3)
+
+
+def cpu_config1():
+    """SURVEY §8d: the oracle's config-1 step (tiny ViT + 2-layer / 4-expert MoE student, 2-layer dense teacher, B = 2, only_kd,
+    fp32) on the host cores: 1 warm-up + 3 timed steps."""
+    from oracle.decoder import DecoderConfig
+    from oracle.llava import LlavaOracle, freeze_like_d2s, mimic_step
+    from oracle.vision import IGNORE_INDEX, IMAGE_TOKEN_INDEX, VisionConfig
+    vc = VisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4, image_size=28, patch_size=14,
+                      select_layer=-2)
+    sc = DecoderConfig(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=2, moe_layers_idx=[0], num_experts=4, top_k_experts=2, capacity_factor=1.5,
+                       eval_capacity_factor=2.0, min_capacity=0, router_aux_loss_coef=0.01)
+    tc = DecoderConfig(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=2)
+    torch.manual_seed(0)
+    st, te = LlavaOracle(sc, vc, moe=True), LlavaOracle(tc, vc, moe=False)
+    freeze_like_d2s(st)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 500, (2, 8), generator=g)
+    ids[:, 2] = IMAGE_TOKEN_INDEX
+    labels = ids.clone()
+    labels[:, :3] = IGNORE_INDEX
+    b = dict(input_ids=ids, attention_mask=torch.ones(2, 8, dtype=torch.bool), labels=labels, images=torch.randn(2, 3, 28, 28, generator=g))
+    st.train(); te.eval()
+    st.set_gate_noise(None)
+    ts = []
+    for i in range(4):
+        st.zero_grad()
+        t0 = time.perf_counter()
+        mimic_step(st, te, b, loss_type="only_kd", align_vocab=512)
+        ts.append(time.perf_counter() - t0)
+    ms = sum(ts[1:]) / 3 * 1e3
+    return {"ms_per_step": round(ms, 2), "samples_per_s": round(2 / (ms * 1e-3), 1), "steps": "1 warm-up + 3 timed, B = 2, only_kd, fp32"}
+
+
 def _mem_total_gb():
     try:
         for line in open("/proc/meminfo"):
@@ -132,7 +228,7 @@ def _mem_total_gb():
     return 0.0
 
 
-def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None):
+def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None, stage="mimic"):
     """The oracle (fp32 PyTorch restatement of the reference, oracle/) timed on this box's host cores on ONE sample of the
     same workload (config 2, B=1, S=2048): teacher forward + student forward/backward + losses (no optimizer step).
 
@@ -172,6 +268,40 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None)
     cb = dict(b, images=b["images"].float())
     o_student.train(); o_teacher.eval()
     o_student.set_gate_noise(None)
+    if stage == "dpo":
+        # config 4 (VERDICT r03 next #6b): ONE chosen / rejected pair through the oracle's preference step at full depth (two
+        # student forward/backward passes + two frozen-model forwards, kto_pair, beta 0.1) and the same pair through the GPU
+        # DPOTrainer — loss, reward term, balance term, rewards and sequence log-probabilities side by side
+        from oracle.llava import dpo_step
+        rj = synthetic_batch(1, 5003)
+        pair = dict(chosen_input_ids=b["input_ids"], chosen_labels=b["labels"], chosen_attention_mask=b["attention_mask"],
+                    rejected_input_ids=rj["input_ids"], rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
+                    images=b["images"])
+        t0 = time.time()
+        _, logs = dpo_step(o_student, o_teacher, dict(pair, images=pair["images"].float()), beta=0.1, loss_type="kto_pair")
+        t_cpu = time.time() - t0
+        tf = 2.0 * mimic_tflop(t_layers=t_l, s_dense=s_l // 2, s_moe=s_l // 2, vit_layers=vit_l)
+        out = {"value": round(1.0 / t_cpu if full else (tf / t_cpu) / (2 * TFLOP_PER_SAMPLE_LEDGER), 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+               "sample": (f"oracle fp32 torch-CPU preference step (kto_pair) on ONE chosen/rejected pair, S=2048 each, "
+                          f"{'FULL depth, the GPU models weights' if full else f'DEPTH-REDUCED to teacher {t_l}/32, student {s_l}/24, ViT {vit_l}/23 layers, scaled by algorithmic FLOPs'}: "
+                          f"{tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {tf / t_cpu:.2f} TFLOP/s")}
+        if full:
+            moes = student.moe_layers()
+            old = [(m.deterministic, m.gate_noise) for m in moes]
+            for m in moes:
+                m.deterministic, m.gate_noise = True, None
+            with torch.no_grad():
+                _, outs = trainer.compute_loss(student, pair, return_outputs=True)
+            for m, (d, n) in zip(moes, old):
+                m.deterministic, m.gate_noise = d, n
+            ld = {}
+            for k in ("loss", "loss/reward", "loss/moe_balance", "rewards/chosen", "rewards/rejected", "rewards/margins",
+                      "logps/chosen", "logps/rejected"):
+                g, c = float(outs[k].detach()), float(logs[k].detach())
+                ld[k] = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "abs": round(abs(g - c), 6),
+                         "rel": round(abs(g - c) / max(abs(c), 1e-30), 6)}
+            out["loss_delta"] = ld
+        return out
     t0 = time.time()
     _, logs, _, _ = mimic_step(o_student, o_teacher, cb, loss_type="kd_lm")
     t_cpu = time.time() - t0
@@ -230,6 +360,10 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None)
     out = {"value": round(value, 5), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
     if loss_delta is not None:
         out["loss_delta"] = loss_delta
+    try:
+        out["config1"] = cpu_config1()
+    except Exception as e:
+        out["config1"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -471,6 +605,9 @@ def main():
         torch.cuda.synchronize()
         gemm_ms = e0.elapsed_time(e1) / 10
         gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
+        del a, w, o
+        in_step = in_step_gemm_aggregate(step, args.warmup + args.steps)
+        optimizer_ms = time_optimizer(gb, opt, world * A)
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
         traffic, traffic_note = None, "no committed PMC pass for this shape"
         tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r03_final_gemm_traffic.json", "r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
@@ -511,15 +648,15 @@ def main():
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": round(gemm_ms, 4),
-                         "whole_step": {"achieved": round(achieved, 1), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                                        "basis": f"{ledger:.2f} algorithmic TFLOP per unit (BASELINE.md) x units/s / n_gpus",
-                                        "executed_tflop_per_sample": round(executed_tflop_per_sample(), 2)}},
+                         "achieved_note": "live micro-launch: 10 launches at the teacher-QKV shape, HIP events on the launch stream",
+                         "in_step": in_step,
+                         "whole_step": whole_step_object(sps / world, args.stage)},
+            "optimizer_ms": optimizer_ms,
             "exchange": exchange_object(dp, opt, args.steps, comm0),
         }
         if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:
-                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer if args.stage == "mimic" else None,
-                                                   args.cpu_baseline if args.stage == "mimic" else "sample", gb=gb)
+                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer, args.cpu_baseline, gb=gb, stage=args.stage)
             except Exception as e:                              # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(out), flush=True)

@@ -1333,10 +1333,12 @@ struct G4Tile {      // one output tile: coordinates, operand windows, this lane
   const bf16_t* Ab; const bf16_t* Bb;
   uint32_t bytesA, bytesB, voA[8], voB[8];
 };
-// PERSIST (round 4): one workgroup per CU walks the tile space (tile = blockIdx.x + i * gridDim.x, XCD-remapped as before).  After a
-// tile's K loop the NEXT tile's first two K tiles are put in flight (LDS-DMA) BEFORE this tile's epilogue, so the operand latency,
-// the workgroup turn-around and the index arithmetic hide under the epilogue's conversions and stores.  Plain launches only (no
-// m_valid / k_valid / split-K: the launcher decides); results are those of the one-tile-per-workgroup form, bit for bit.
+// PERSIST (round 4): one workgroup per CU walks the tile space (tile = blockIdx.x + i * gridDim.x, XCD-remapped as before) and its
+// operand stream never stops: the K loop's look-ahead (LDS-DMA of K tile t+2, fragment reads of t+1) runs on INTO THE NEXT
+// OUTPUT TILE (G4_ASM_LOOP_P switches the two descriptors when it passes the end of K), so a tile's epilogue starts with the
+// next tile's first fragments in registers and its second K tile in flight, and its C stores drain under the next tile's first
+// MFMAs — no workgroup turn-around, no prologue latency, no store drain on the critical path.  Plain launches with K % 64 == 0,
+// K >= 256 (the launcher decides); results are those of the one-tile-per-workgroup form, bit for bit.
 template <int MODE, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4_kernel(GemmP p) {
   constexpr int TN = (MODE == 1) ? 128 : 256;
@@ -1439,13 +1441,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ptotal = PERSIST ? p.ptotal : (int)gridDim.x;
   if (!setup(pbid, ptotal, T)) return;                     // (persistent launches carry no m_valid: every tile id is live)
   stage_tiles01(T);
+  bf16x8 fa[2][8], fb[2][8];
+  // PERSIST: what the K loop carries from one tile to the next — the LDS stage parity (fragment addresses, LDS-DMA base) and the
+  // first fragments of the next tile (its last pass already read them) — and staging offsets that do not depend on the tile (rows
+  // past a ragged edge are cut by the descriptor's byte count instead of per-lane out-of-range markers)
+  uint32_t g4_ra0 = 0, g4_ra1 = 0, g4_rb0 = 0, g4_rb1 = 0, g4_dma = 0;
+  bool first = true;
   for (;;) {                                               // ---- one output tile per pass (exactly one pass unless PERSIST)
   const int id = T.id, bz = T.bz, split = T.split, Mv = T.Mv, Kv = T.Kv, row0 = T.row0, col0 = T.col0, nkt = T.nkt;
   const bf16_t* Ab = T.Ab; const bf16_t* Bb = T.Bb;
   const uint32_t bytesA = T.bytesA, bytesB = T.bytesB;
   uint32_t voA[8], voB[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { voA[j] = T.voA[j]; voB[j] = T.voB[j]; }
+  for (int j = 0; j < 8; ++j) {
+    if constexpr (!PERSIST) { voA[j] = T.voA[j]; voB[j] = T.voB[j]; }
+    else {   // offsets that do not depend on the tile (a ragged edge is cut by the descriptor's byte count), recomputed per tile from
+             // the laundered lane id so that they are not carried through the epilogue
+      const int lr = (j * 4 + wave) * 8 + (lane >> 3);
+      voA[j] = (uint32_t)((lr * p.lda + cchunk * 8) * 2);
+      const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
+      if (MODE != 1) voB[j] = (uint32_t)(((grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3)) * p.ldb + cchunk * 8) * 2);
+      else voB[j] = (uint32_t)((((long long)(grp64 & 1) * p.N + (grp64 >> 1) * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3)) * p.ldb + cchunk * 8) * 2);
+    }
+  }
   __amdgpu_buffer_rsrc_t rsA = rsrc_of(Ab, bytesA);
   __amdgpu_buffer_rsrc_t rsB = rsrc_of(Bb, bytesB);
   (void)id; (void)split;
@@ -1463,7 +1481,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int abase = (wr * 128 + li) * 128, bbase = 32768 + (wc * 128 + li) * 128;
   const int ph[2] = {((g) ^ (li & 7)) * 16, ((4 + g) ^ (li & 7)) * 16};
 #endif
-  bf16x8 fa[2][8], fb[2][8];
 #ifndef G4_DEEP
 #define G4_DEEP 1
 #endif
@@ -1501,14 +1518,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
 
-  // the first two K tiles were put in flight by stage_tiles01 (before the loop, or before the previous tile's epilogue)
-  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // loads and the previous tile's stores share the counter and retire out of order: no counted wait here
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed (tile 1's 16 pieces may still fly)
-  G4_BARRIER();
-  {
+  // the first two K tiles were put in flight by stage_tiles01; a persistent workgroup's LATER tiles arrive primed: the previous
+  // tile's K loop fetched their first two K tiles with its look-ahead and read the first fragments in its last pass
+  if (!PERSIST || first) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // tile 0 landed (tile 1's 16 pieces may still fly)
+    G4_BARRIER();
     const char* s = smem + ph[0];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * G4_FSTR); fb[0][i] = *(const bf16x8*)(s + bbase + i * G4_FSTR); }
+  } else {
+    // primed by the previous tile's K loop: K tile 0 of THIS tile sits in the stage g4_ra1 / g4_rb1 point at (k-half 1: the k-half-0
+    // chunk is the address with bit 6 flipped), landed and barrier-ed.  Re-reading 16 fragments costs less than carrying 64 registers
+    // through the epilogue (hipcc spills them through scratch)
+    typedef __attribute__((address_space(3))) const bf16x8* lds_frag_t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fa[0][i] = *(lds_frag_t)(uintptr_t)((g4_ra1 ^ 64u) + i * G4_FSTR);
+      fb[0][i] = *(lds_frag_t)(uintptr_t)((g4_rb1 ^ 64u) + i * G4_FSTR);
+    }
   }
   for (int t = 0; t < nkt; ++t) {
     kstep(0, t, 1, false, 0);                              // k-step 0; reads this tile's k-step-1 operands
@@ -1560,14 +1587,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define G4_MFMA(cur, idx) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(idx) >> 3][(idx) & 7]) : "v"(fb[cur][(idx) & 7]), "v"(fa[cur][(idx) >> 3]))
 #define G4_SB() __builtin_amdgcn_sched_barrier(0)
 
-  // the first two K tiles were put in flight by stage_tiles01 (before the loop, or before the previous tile's epilogue)
-  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // loads and the previous tile's stores share the counter and retire out of order: no counted wait here
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed (tile 1's 16 pieces may still fly)
-  G4_BARRIER();
-  {
+  // the first two K tiles were put in flight by stage_tiles01; a persistent workgroup's LATER tiles arrive primed: the previous
+  // tile's K loop fetched their first two K tiles with its look-ahead and read the first fragments in its last pass
+  if (!PERSIST || first) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // tile 0 landed (tile 1's 16 pieces may still fly)
+    G4_BARRIER();
     const char* s = smem + ph[0];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[0][i] = *(const bf16x8*)(s + abase + i * G4_FSTR); fb[0][i] = *(const bf16x8*)(s + bbase + i * G4_FSTR); }
+  } else {
+    // primed by the previous tile's K loop: K tile 0 of THIS tile sits in the stage g4_ra1 / g4_rb1 point at (k-half 1: the k-half-0
+    // chunk is the address with bit 6 flipped), landed and barrier-ed.  Re-reading 16 fragments costs less than carrying 64 registers
+    // through the epilogue (hipcc spills them through scratch)
+    typedef __attribute__((address_space(3))) const bf16x8* lds_frag_t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fa[0][i] = *(lds_frag_t)(uintptr_t)((g4_ra1 ^ 64u) + i * G4_FSTR);
+      fb[0][i] = *(lds_frag_t)(uintptr_t)((g4_rb1 ^ 64u) + i * G4_FSTR);
+    }
   }
   auto run_loop = [&](auto k64_t) {
   for (int t = 0; t < nkt; ++t) {
@@ -1638,22 +1675,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #if G4_ASM
   // K % 64 == 0 (every launch of the step on this kernel): the loop as ONE hand-placed asm statement (gemm4_loop_asm.h, written
   // by tools/gen_gemm4_loop.py); the hipcc-scheduled loop above stays for ragged reduction lengths and as the A/B arm (G4_ASM=0)
+  G4Tile Nx;
+  bool more = false;
   if ((Kv & 63) == 0) {
     if (nkt > 0) {
       const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-      uint32_t g4_ra1 = lds0 + ph[1] + abase, g4_rb1 = lds0 + ph[1] + bbase;                         // tile 0: stage 0, k-half 1
-      uint32_t g4_ra0 = lds0 + G4_STAGE + ph[0] + abase, g4_rb0 = lds0 + G4_STAGE + ph[0] + bbase;   // tile 1: stage 1, k-half 0
+      if (!PERSIST || first) {
+        g4_ra1 = lds0 + ph[1] + abase; g4_rb1 = lds0 + ph[1] + bbase;                         // tile 0: stage 0, k-half 1
+        g4_ra0 = lds0 + G4_STAGE + ph[0] + abase; g4_rb0 = lds0 + G4_STAGE + ph[0] + bbase;   // tile 1: stage 1, k-half 0
+        g4_dma = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+      }
       uint32_t g4_nk = __builtin_amdgcn_readfirstlane(nkt), g4_koff = 256u;
       const uint32_t g4_klim = __builtin_amdgcn_readfirstlane(Kv * 2);
-      uint32_t g4_dma = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
       const unsigned long long pa = (unsigned long long)Ab, pb = (unsigned long long)Bb;
       const uint32_t g4_dA[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffffu)),
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)bytesA), 0x00020000u};
       const uint32_t g4_dB[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pb >> 32) & 0xffffu)),
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)bytesB), 0x00020000u};
-      G4_ASM_LOOP();
+      if constexpr (PERSIST) {
+        // the NEXT tile's operand windows: the loop's look-ahead moves onto them when it runs off the end of this tile's K range
+        // (no next tile: zero records, nothing is fetched)
+        pbid += (int)gridDim.x;
+        more = pbid < ptotal;
+        uint32_t g4_dAn[3] = {g4_dA[0], g4_dA[1], 0u}, g4_dBn[3] = {g4_dB[0], g4_dB[1], 0u};
+        if (more) {
+          setup(pbid, ptotal, Nx);
+          const unsigned long long na = (unsigned long long)Nx.Ab, nb = (unsigned long long)Nx.Bb;
+          g4_dAn[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)na); g4_dAn[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((na >> 32) & 0xffffu));
+          g4_dAn[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)Nx.bytesA);
+          g4_dBn[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb); g4_dBn[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nb >> 32) & 0xffffu));
+          g4_dBn[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)Nx.bytesB);
+        }
+        G4_ASM_LOOP_P();
+      } else {
+        G4_ASM_LOOP();
+      }
     }
-  } else run_loop(std::false_type{});
+  } else if constexpr (!PERSIST) run_loop(std::false_type{});       // (persistent launches: K % 64 == 0, launcher-checked)
 #else
   if ((Kv & 63) == 0) run_loop(std::true_type{}); else run_loop(std::false_type{});
 #endif
@@ -1661,30 +1719,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef G4_SB
 #endif
   // the asm MFMAs are invisible to the hazard recognizer: let the last accumulator writes retire before reading them
-  asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+  if constexpr (PERSIST) asm volatile("s_nop 15\n s_nop 15" ::: "memory");          // (the next tile's K tile 1 stays in flight)
+  else asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
 
-  // PERSIST: everything below is lane / wave arithmetic that does not change from tile to tile, and hipcc hoists all of it out of
-  // the tile loop — i.e. ACROSS the K loop, where 404 of the 512 registers are taken: ~100 spilled VGPRs, reloaded through scratch
-  // behind the LDS-DMA queue (measured: -6 ... -12 %).  Laundering the lane / wave ids here makes their derived values new per tile.
+  // PERSIST: the epilogue's addresses are lane / wave arithmetic that does not change from tile to tile, and hipcc hoists all of
+  // it out of the tile loop — i.e. ACROSS the K loop, where 404 of the 512 registers are taken: ~100 spilled VGPRs, reloaded
+  // through scratch behind the LDS-DMA queue (measured: -6 ... -12 %).  Laundering the ids here makes the derived values per tile.
   if constexpr (PERSIST) {
     asm volatile("" : "+v"(tid), "+s"(wave));
     lane = tid & 63; li = lane & 15; g = lane >> 4;
     cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
     wr = wave >> 1; wc = wave & 1;
-  }
-
-  // PERSIST: the next tile's first two K tiles go in flight now, under this tile's epilogue.  The barrier: every wave has drained
-  // its LDS-DMA (the vmcnt(0) above, tiles past the end included) and finished its fragment reads, so both stages are free.
-  G4Tile Nx;
-  bool more = false;
-  if constexpr (PERSIST) {
-    pbid += (int)gridDim.x;
-    more = pbid < ptotal;
-    if (more) {
-      setup(pbid, ptotal, Nx);
-      G4_BARRIER();
-      stage_tiles01(Nx);
-    }
   }
 #undef G4_BARRIER
 
@@ -1887,6 +1932,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int x = 0; x < 16; ++x) if (cb + x < p.N) cp[x] = f2bf(v[x]);
     }
+    // persistent form: 64 registers of the next tile's fragments stay live across the epilogue; left free, hipcc converts all 16
+    // pieces before the first store (128 packed registers) and spills the fragments around it
+    if constexpr (PERSIST) __builtin_amdgcn_sched_barrier(0);
   };
   auto epi_f32_acc = [&](const int gq, const int mt) {       // weight gradients: fp32 C +=, vector path
     const int cb = col0 + wc * 128 + gq * 64 + g * 16;
@@ -2096,8 +2144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   };
   epilogue();
-  if (!PERSIST || !more) return;
+  if constexpr (!PERSIST) return;
+  if (!more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }       // (the dead look-ahead pieces of the last tile)
   T = Nx;
+  first = false;
   }                                                        // tile loop
 }
 
@@ -2188,7 +2238,11 @@ static int gemm_cus() {
 static bool gemm_persist(const GemmP& p, long long nwg) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("LMOD_GEMM_PERSIST"); on = e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT; }
-  return on && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus();
+  // measured (profiles/r04_gemm_loop.md): +1.5 % at 24 rounds of the CUs (teacher QKV), +4.8 % at 12 rounds with K 2048, level or
+  // slightly behind at 4 - 8 rounds, where a static tile-to-CU assignment loses what the hardware dispatcher's dynamic one balances
+  static int min_rounds = -1;
+  if (min_rounds < 0) { const char* e = getenv("LMOD_GEMM_PERSIST_ROUNDS"); min_rounds = e ? atoi(e) : 10; }
+  return on && G4_ASM && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg >= (long long)min_rounds * gemm_cus() && (p.K & 63) == 0 && p.K >= 256;
 }
 template <int MODE>
 static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {

@@ -108,9 +108,23 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Launch trace (measurement only, off by default): `TRACE = {"names": {...}, "rows": []}` makes `call` bracket every launch of
+# the named entry points with two events on the launch stream and keep (name, integer arguments, start, stop).  bench.py uses it
+# for ONE extra, untimed step: the in-step aggregate rate of the dominant kernel (sum of flops / sum of durations).
+TRACE = None
+
+
 def call(name, *args):
     """Invoke `name` on the current torch stream; raise on a non-zero status."""
     lib = load()
-    rc = getattr(lib, name)(*args, stream())
+    if TRACE is not None and name in TRACE["names"]:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, stream())
+        e1.record()
+        TRACE["rows"].append((name, tuple(a if isinstance(a, int) else (0 if a is None else 1) for a in args), e0, e1))
+    else:
+        rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

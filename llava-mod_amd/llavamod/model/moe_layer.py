@@ -163,6 +163,9 @@ class MoE(nn.Module):
             from ..engine import expert_parallel_group
             self.ep_group = expert_parallel_group(ep)
         group = self.ep_group if ep > 1 else None
+        if group is None and os.environ.get("LMOD_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized():
+            group = dist.group.WORLD      # a world of ONE rank: the exchange is the identity but goes through the backend's own
+                                          # all_to_all_single (RCCL on a GPU box) — the N > 1 code path on the hardware there is
         router_params = [wg_p for wg_p in [self.deepspeed_moe.gate.wg.weight] if wg_p.requires_grad]
         disp, w1, w2, l_aux, counts = ops.MoERoute.apply(x, spec, noise, *router_params)
         st = spec.last_state
@@ -185,9 +188,15 @@ class MoE(nn.Module):
         self.last_ep_plan = pl
         packed = ops.RowGather.apply(disp, pl.send_idx, pl.send_inv)                         # [Ls, H] live rows only
         recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, group)          # [Lr, H]
-        recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)                        # slabs [ep*El*C, H]
-        y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rr.contiguous(), *expert_params)
-        y_p = ops.RowGather.apply(y.view(ep * El * C, H), pl.recv_inv, pl.recv_slab)         # live outputs [Lr, H]
+        if El == 1:
+            # ONE local expert (config 5: 8 experts on 8 ranks): the packed live rows ARE its input — no capacity slabs on the
+            # receiving side, no row masks, no zero-filled dead rows: the dense fused-SwiGLU block on [Lr, H] (plain GEMM launches,
+            # K = Lr weight gradients).  A rank that received nothing skips the block (its expert's gradient span stays zero).
+            y_p = ops.MLPBlock.apply(recv_p, spec, *expert_params) if recv_p.shape[0] > 0 else recv_p
+        else:
+            recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)                    # slabs [ep*El*C, H]
+            y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rr.contiguous(), *expert_params)
+            y_p = ops.RowGather.apply(y.view(ep * El * C, H), pl.recv_inv, pl.recv_slab)     # live outputs [Lr, H]
         back_p = ops.AllToAllRows.apply(y_p, pl.out_splits, pl.in_splits, group)             # [Ls, H]
         back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)                         # [E*C, H], zero on dead slots
         out = ops.MoECombine.apply(back, w1, w2, st)

@@ -771,12 +771,17 @@ class ExpertFFN(torch.autograd.Function):
         I = ctx.I
         dy = dy.contiguous()
         gu_t, down_t = sp.gu.transposed(), sp.down.transposed()
-        dact = torch.empty((ep, El, C, I), device=x.device, dtype=BF16)
+        fused_bwd = (I % 16 == 0)          # down-projection dgrad + SwiGLU backward in ONE grouped launch per local expert (as MoEBlock)
+        dact = None if fused_bwd else torch.empty((ep, El, C, I), device=x.device, dtype=BF16)
+        dgu = torch.empty_like(gu)
         for le in range(El):
             mv = rows[:, le].contiguous() if rows is not None else None
             dt = down_t[le] if sp.down.stacked else down_t
-            K.gemm_nt(dy[:, le], dt, out=dact[:, le], M=C, N=I, K=H, lda=H, ldb=dt.stride(0), ldc=I, batch=ep,
-                      strides=(El * C * H, 0, El * C * I), m_valid=mv)
+            if fused_bwd:                   # batch = source ranks (shared weights); dead rows up to the next multiple of 8 are zeroed
+                K.gemm_swiglu_bwd(dy[:, le], dt, gu[:, le], out=dgu[:, le], m_valid=mv, K=H)
+            else:
+                K.gemm_nt(dy[:, le], dt, out=dact[:, le], M=C, N=I, K=H, lda=H, ldb=dt.stride(0), ldc=I, batch=ep,
+                          strides=(El * C * H, 0, El * C * I), m_valid=mv)
         gu2 = gu.view(ep * El * C, 2 * I)
         rflat = rows.reshape(-1).contiguous() if rows is not None else None
         if sp.down.requires_grad:
@@ -791,9 +796,9 @@ class ExpertFFN(torch.autograd.Function):
                         K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
                                   out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
             sp.down.grad_done()
-        dgu = torch.empty_like(gu)
-        dgu2 = dgu.view(ep * El * C, 2 * I)
-        K.swiglu_bwd(dact.view(ep * El * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rflat)
+        if not fused_bwd:
+            dgu2 = dgu.view(ep * El * C, 2 * I)
+            K.swiglu_bwd(dact.view(ep * El * C, I), gu2[:, :I], gu2[:, I:], dgu2[:, :I], dgu2[:, I:], seg_rows=C, seg_valid=rflat)
         dx = torch.empty_like(x)
         for le in range(El):
             mv = rows[:, le].contiguous() if rows is not None else None

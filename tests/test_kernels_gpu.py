@@ -105,6 +105,30 @@ def test_gemm_big_tile_k64_hand_placed_loop(K_):
     close(act, F.silu(g.to(BF).float()).to(BF).float() * u.to(BF).float(), f"k64 fused swiglu K={K_}")
 
 
+@pytest.mark.parametrize("K_", [256, 320, 1024])
+def test_gemm_persistent_tile_walk(K_):
+    # more 256x256 tiles than CUs (18 x 17 = 306 > 256): the persistent four-wave kernel — one workgroup per CU walks several
+    # tiles, its K loop's look-ahead runs on into the NEXT tile's operand windows.  Ragged M and N edges (rows / columns past the
+    # edge are cut by the buffer descriptors' byte counts on this path), K of 4, 5 and 16 K tiles, second tiles of every parity;
+    # plain, bias + activation, and the fused SwiGLU forward (128-column tiles: 18 x 18).
+    M, N = 4500, 4300 - 4
+    a, b, bias = rnd(M, K_, seed=90 + K_), rnd(N, K_, seed=91 + K_), rnd(N, seed=92)
+    ref = a.float() @ b.float().t()
+    got = K_gemm(a, b)
+    close(got, ref, f"persistent gemm K={K_}")
+    assert torch.equal(got, K_gemm(a, b))
+    pre = (ref + bias.float()).to(BF).float()
+    close(K_gemm(a, b, bias=bias, act=1), F.gelu(pre), f"persistent gemm+bias+gelu K={K_}")
+    eye = torch.eye(M, K_, device=DEV, dtype=BF)
+    g2 = K_gemm(eye, b)
+    assert torch.equal(g2[:K_].float(), b.float().t()) and g2[K_:].abs().max().item() == 0
+    I = 2296
+    wgu = rnd(2 * I, K_, seed=93 + K_)
+    gu_ref = K.gemm_nt(a, wgu)
+    act, gu = K.gemm_swiglu(a, wgu, want_gu=True)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:]))
+
+
 def test_gemm_bias_act_f32_accumulate():
     M, N, K_ = 200, 264, 320
     a, b, bias = rnd(M, K_, seed=3), rnd(N, K_, seed=4), rnd(N, seed=5)

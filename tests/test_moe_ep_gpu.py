@@ -49,3 +49,41 @@ def test_decomposed_equals_fused(E, k, T, live):
     for n in w1:
         d = (w1[n] - w2[n]).abs().max().item()
         assert d <= 1e-5 * max(1.0, w1[n].abs().max().item()), (n, d)
+
+
+def test_full_slab_exchange_runs_without_a_host_sync():
+    """the expert-parallel layer with the whole-slab exchange (`ep_live_rows = False`, DeepSpeed's own wire
+    format) never reads anything back to the host — routing, counts exchange, local experts (live rows only, counts read ON THE
+    DEVICE as grouped-GEMM `m_valid`), exchange back, combine, and the whole backward run under
+    `torch.cuda.set_sync_debug_mode("error")`.  The live-row form (default) pays exactly one read-back per layer and direction of
+    the forward (the unequal split sizes of `all_to_all_single` are host integers — the same point where DeepSpeed's gate syncs
+    `exp_counts`); which form wins at 8 GPUs is a bytes-vs-sync trade the multi-GPU bench decides (`LMOD_EP_FULL_SLABS=1`)."""
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
+    from llavamod.model.moe_layer import MoE
+    torch.manual_seed(0)
+    mlp = init_normal_(Qwen2MLP(Qwen2Config(hidden_size=256, intermediate_size=512), "cuda"), std=0.05, seed=1)
+    m = MoE(256, mlp, num_experts=8, k=2, capacity_factor=1.5, min_capacity=0)
+    m.force_decomposed, m.ep_live_rows = True, False
+    m.train()
+    x = (torch.randn(1000, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    dout = torch.randn(1000, 256, device="cuda").to(torch.bfloat16)
+    xi = x.clone().requires_grad_(True)
+    out, l_aux, _ = m(xi)                                        # warm-up: lazy allocations / first-use setup may sync
+    (out.float() * dout.float()).sum().backward()
+    torch.cuda.synchronize()
+    xi = x.clone().requires_grad_(True)
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out, l_aux, _ = m(xi)
+        ((out.float() * dout.float()).sum() + 2.0 * l_aux).backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(xi.grad.float()).all())
+    m.ep_live_rows = True                                        # the live-row form does read the counts back: it must trip the detector
+    with pytest.raises(RuntimeError):
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            m(x.clone().requires_grad_(True))
+        finally:
+            torch.cuda.set_sync_debug_mode("default")

@@ -905,6 +905,39 @@ def _rccl_world1_worker(port, q):
         bad[mode] = [k for k in res["plain"] if not torch.equal(res["plain"][k], res[mode][k])]
     far = [k for k in res["plain"] if (res["plain"][k] - res["zero2_bf16"][k]).abs().max() > 2.5e-3]   # lr-sized Adam steps
     bad["zero2_bf16"] = far
+    # the expert-parallel exchange through RCCL (VERDICT r03 next #6c): with LMOD_FORCE_DIST the decomposed MoE path sends its
+    # counts and rows through dist.all_to_all_single on the world-of-one group — packed live rows (unequal splits) and whole
+    # slabs — and must reproduce the fused single-GPU block bit for bit (output, aux loss, counts, input gradient)
+    import copy
+    from llavamod import engine
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
+    from llavamod.model.moe_layer import MoE
+    torch.manual_seed(0)
+    mlp = init_normal_(Qwen2MLP(Qwen2Config(hidden_size=256, intermediate_size=512), "cuda"), std=0.05, seed=1)
+    fused = MoE(256, mlp, num_experts=8, k=2, capacity_factor=1.0, min_capacity=0)
+    with torch.no_grad():
+        for i, e in enumerate(fused.deepspeed_moe.experts.deepspeed_experts):
+            for p_ in e.parameters():
+                p_.mul_(1.0 + 0.1 * i)
+        fused.deepspeed_moe.gate.wg.weight.normal_(0, 0.5)
+    x = (torch.randn(1000, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    dout = torch.randn(1000, 256, device="cuda").to(torch.bfloat16)
+    outs = []
+    before = {k: list(v) for k, v in engine.COMM.items()}
+    for live in (None, True, False):
+        m = copy.deepcopy(fused)
+        if live is not None:
+            m.force_decomposed, m.ep_live_rows = True, live
+        m.train(); m.deterministic = True
+        xi = x.clone().requires_grad_(True)
+        o, l_aux, counts = m(xi)
+        (o.float() * dout.float()).sum().backward()
+        outs.append((o.detach(), l_aux.detach(), counts, xi.grad))
+    sent = engine.COMM.get("all_to_all", [0, 0])[0] - before.get("all_to_all", [0, 0])[0]
+    bad["ep_rccl"] = [] if sent >= 8 else [f"only {sent} all_to_all calls reached the backend"]
+    for tag, r in (("live", outs[1]), ("slabs", outs[2])):
+        if not (torch.equal(outs[0][0], r[0]) and torch.equal(outs[0][1], r[1]) and torch.equal(outs[0][2], r[2]) and torch.equal(outs[0][3], r[3])):
+            bad["ep_rccl"].append(tag)
     dist.barrier()
     dist.destroy_process_group()
     q.put(bad)

@@ -27,8 +27,9 @@ def _ep_worker(rank, world, port, q):
     from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2MLP, init_normal_
     from llavamod.model.moe_layer import MoE
     init_distributed()
-    dev, H, I, E, T = "cuda", 256, 512, 4, 600
+    dev, H, I, T = "cuda", 256, 512, 600
     cfg = Qwen2Config(hidden_size=H, intermediate_size=I)
+    E = 4
 
     def make(ep):
         mlp = init_normal_(Qwen2MLP(cfg, dev), std=0.05, seed=1)
@@ -60,7 +61,9 @@ def _ep_worker(rank, world, port, q):
     def grads(m):
         return {n: p.main_grad.clone() for n, p in m.named_parameters() if getattr(p, "main_grad", None) is not None}
 
-    for live in (True, False):
+    # E 4: two local experts per rank (capacity slabs on the receiving side); E 2: ONE local expert per rank — config 5's shape —
+    # whose live-row form runs the dense fused block on the packed rows (no slabs, no row masks)
+    for E, live in ((4, True), (4, False), (2, True), (2, False)):
         # reference: ALL experts in one process (fused block).  DeepSpeed routes every rank's tokens with that rank's own capacity, so
         # the reference for rank r's outputs is the full layer on rank r's tokens; an expert's weight gradient sums BOTH ranks' tokens.
         ref = make(1)
@@ -83,12 +86,13 @@ def _ep_worker(rank, world, port, q):
         assert (o.float() - o_ref.float()).abs().max().item() <= 2 ** -7 * scale, "expert-parallel output"
         assert (gx.float() - gx_ref.float()).abs().max().item() <= 2 ** -6 * gx_ref.float().abs().max().item(), "input gradient"
         assert len(g_ep) == 3 * (E // 2) + 1
+        nl = E // 2
         for n, gv in g_ep.items():
             if "gate.wg" in n:                                 # replicated: this rank's tokens only (data-parallel all-reduce comes later)
                 rv = gate_ref
             else:                                              # local expert i is global expert rank * 2 + i
                 i = int(n.split("deepspeed_experts.")[1].split(".")[0])
-                rv = g_ref[n.replace(f"deepspeed_experts.{i}.", f"deepspeed_experts.{rank * 2 + i}.")]
+                rv = g_ref[n.replace(f"deepspeed_experts.{i}.", f"deepspeed_experts.{rank * nl + i}.")]
             err = (gv - rv).abs().max().item()
             assert err <= 2e-3 * max(1e-6, rv.abs().max().item()), (live, n, err, rv.abs().max().item())
     dist.barrier()
@@ -97,7 +101,7 @@ def _ep_worker(rank, world, port, q):
 
 
 def test_expert_parallel_layer_two_ranks_share_the_gpu():
-    """ep_size 2, 4 experts (2 per rank), top-2, capacity factor 1.5: forward output, aux loss, expert counts, input gradient, router
+    """ep_size 2, 4 experts (2 per rank) and 2 experts (1 per rank: the packed single-expert form), top-2, capacity factor 1.5: forward output, aux loss, expert counts, input gradient, router
     gradient and the local experts' weight gradients against the single-process 4-expert layer — live-row exchange and full slabs."""
     from test_dp_gloo import _spawn
     _spawn(_ep_worker, timeout=400)

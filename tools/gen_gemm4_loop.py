@@ -29,6 +29,9 @@ ap.add_argument("--variant", default="b2")
 ap.add_argument("--order", default="mn", help="mn: 8 consecutive MFMAs share the A-side fragment (src1), round 3's order; nm: they share the "
                                           "B-side fragment (src0), the order of hipBLASLt's kernel")
 ap.add_argument("--split-barrier", type=int, default=0, help="1: the wait and its s_barrier one MFMA apart")
+ap.add_argument("--persist", type=int, default=0, help="1: also emit G4_ASM_LOOP_P(): when the look-ahead LDS-DMA runs off the end of the K "
+                                                       "range it SWITCHES to the next output tile's operand windows (descriptor words dAn / dBn, offset 0) "
+                                                       "instead of fetching nothing: a persistent workgroup's operand stream never stops")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd", "csrc",
                                               "gemm4_loop_asm.h"))
 args = ap.parse_args()
@@ -124,79 +127,102 @@ sched[s1[1]].append(f"v_xor_b32 %[rb1], {STAGE}, %[rb1]")
 s0 = free_slot(last_r0 + 1, 2)
 sched[s0[0]].append(f"v_xor_b32 %[ra0], {STAGE}, %[ra0]")
 sched[s0[1]].append(f"v_xor_b32 %[rb0], {STAGE}, %[rb0]")
-tail = free_slot(max(last_piece + 1, s0[1] + 1), 3)
-sched[tail[0]] += [f"s_xor_b32 %[dma], %[dma], {STAGE}", "s_add_u32 %[koff], %[koff], 128"]
-sched[tail[1]] += ["s_cmp_lt_u32 %[koff], %[klim]", "s_cselect_b32 s86, %[dA2], 0"]        # tile t+3 past the end: zero records
-sched[tail[2]] += ["s_cselect_b32 s90, %[dB2], 0", "s_sub_u32 %[nk], %[nk], 1"]
-assert tail[2] <= 126
-sched[126] += ["s_cmp_lg_u32 %[nk], 0"]
-sched[127] += ["s_waitcnt lgkmcnt(0)", "s_cbranch_scc1 1b"]
-for i in range(128):
-    assert len(sched[i]) <= 2 or any("s_barrier" in s for s in sched[i]), (i, sched[i])
+import copy
+base_sched = copy.deepcopy(sched)
 
-if args.split_barrier:
-    for i in [j for j in range(127) if "s_barrier" in sched[j]]:
-        if True:
+
+def build(persist):
+    global sched
+    sched = copy.deepcopy(base_sched)
+    if not persist:
+        tail = free_slot(max(last_piece + 1, s0[1] + 1), 3)
+        sched[tail[0]] += [f"s_xor_b32 %[dma], %[dma], {STAGE}", "s_add_u32 %[koff], %[koff], 128"]
+        sched[tail[1]] += ["s_cmp_lt_u32 %[koff], %[klim]", "s_cselect_b32 s86, %[dA2], 0"]    # tile t+3 past the end: zero records
+        sched[tail[2]] += ["s_cselect_b32 s90, %[dB2], 0", "s_sub_u32 %[nk], %[nk], 1"]
+        assert tail[2] <= 126
+        entry = ["s_cmp_lt_u32 %[koff], %[klim]", "s_cselect_b32 s86, %[dA2], 0", "s_cselect_b32 s90, %[dB2], 0"]
+    else:
+        # look-ahead past the end of K: the DMA window moves to the NEXT tile (offset 0).  SCC = "still inside this tile"
+        sw = ["s_cmp_lt_u32 %[koff], %[klim]", "s_cselect_b32 %[koff], %[koff], 0",
+              "s_cselect_b32 s84, s84, %[dAn0]", "s_cselect_b32 s85, s85, %[dAn1]", "s_cselect_b32 s86, s86, %[dAn2]",
+              "s_cselect_b32 s88, s88, %[dBn0]", "s_cselect_b32 s89, s89, %[dBn1]", "s_cselect_b32 s90, s90, %[dBn2]"]
+        body = [f"s_xor_b32 %[dma], %[dma], {STAGE}", "s_sub_u32 %[nk], %[nk], 1", "s_add_u32 %[koff], %[koff], 128"] + sw
+        tail = free_slot(max(last_piece + 1, s0[1] + 1), (len(body) + 1) // 2)
+        assert tail[-1] <= 125, tail
+        for k, ins in enumerate(body):
+            sched[tail[k // 2]].append(ins)
+        entry = sw
+    sched[126] += ["s_cmp_lg_u32 %[nk], 0"]
+    sched[127] += ["s_waitcnt lgkmcnt(0)", "s_cbranch_scc1 1b"]
+    for i in range(128):
+        assert len(sched[i]) <= 2 or any("s_barrier" in x for x in sched[i]), (i, sched[i])
+    if args.split_barrier:
+        for i in [j for j in range(127) if "s_barrier" in sched[j]]:
             k = sched[i].index("s_barrier")
             sched[i] = sched[i][:k] + sched[i][k + 1:]        # (an M0 write behind it stays: one MFMA ahead of its LDS-DMA)
             sched[i + 1] = ["s_barrier"] + sched[i + 1]
-    for i in range(128):                          # an M0 write must still sit exactly one MFMA ahead of its LDS-DMA
+    for i in range(128):                          # an M0 write must sit exactly one MFMA ahead of its LDS-DMA
         for ins in sched[i]:
             if ins.startswith("buffer_load"):
                 assert any(x.startswith("s_add_u32 m0") for x in sched[i - 1]), i
+    lines = ["s_mov_b32 s84, %[dA0]", "s_mov_b32 s85, %[dA1]", "s_mov_b32 s86, %[dA2]", "s_mov_b32 s87, %[dA3]",
+             "s_mov_b32 s88, %[dB0]", "s_mov_b32 s89, %[dB1]", "s_mov_b32 s90, %[dB2]", "s_mov_b32 s91, %[dB3]"] + entry + \
+            ["s_waitcnt lgkmcnt(0)", "1:"]
+    n_head = len(lines)
+    for i in range(128):
+        lines.append(mfma(i))
+        lines += sched[i]
+    outs, ins = [], []
+    for mt in range(8):
+        for nt in range(8):
+            outs.append(f'[c{mt}_{nt}] "+a"(acc[{mt}][{nt}])')
+    for i in range(8):
+        outs.append(f'[a0_{i}] "+v"(fa[0][{i}])')
+    for i in range(8):
+        outs.append(f'[b0_{i}] "+v"(fb[0][{i}])')
+    for i in range(8):
+        outs.append(f'[a1_{i}] "=&v"(fa[1][{i}])')
+    for i in range(8):
+        outs.append(f'[b1_{i}] "=&v"(fb[1][{i}])')
+    for r in ("ra0", "ra1", "rb0", "rb1"):
+        outs.append(f'[{r}] "+v"(g4_{r})')
+    for r in ("nk", "koff", "dma"):
+        outs.append(f'[{r}] "+s"(g4_{r})')
+    for i in range(8):
+        ins.append(f'[va{i}] "v"(voA[{i}])')
+    for i in range(8):
+        ins.append(f'[vb{i}] "v"(voB[{i}])')
+    ins.append('[klim] "s"(g4_klim)')
+    for i in range(4):
+        ins.append(f'[dA{i}] "s"(g4_dA[{i}])')
+    for i in range(4):
+        ins.append(f'[dB{i}] "s"(g4_dB[{i}])')
+    if persist:
+        for i in range(3):
+            ins.append(f'[dAn{i}] "s"(g4_dAn[{i}])')
+        for i in range(3):
+            ins.append(f'[dBn{i}] "s"(g4_dBn[{i}])')
+    clob = ['"memory"', '"scc"'] + [f'"s{i}"' for i in range(84, 92)]
+    n_dma = sum(1 for l in lines if "buffer_load" in l)
+    n_rd = sum(1 for l in lines if "ds_read" in l)
+    n_mf = sum(1 for l in lines if "v_mfma" in l)
+    assert (n_dma, n_rd, n_mf) == (16, 32, 128), (n_dma, n_rd, n_mf)
+    name = "G4_ASM_LOOP_P" if persist else "G4_ASM_LOOP"
+    H = [f"// {name}: per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l)} barriers, "
+         f"{len(lines) - n_head - n_mf} other instructions" + (" (look-ahead switches to the next tile's operand windows)" if persist else ""),
+         f"#define {name}() asm volatile( \\"]
+    for l in lines:
+        H.append(f'    "{l}\\n\\t" \\')
+    H.append("    : " + ", ".join(outs) + " \\")
+    H.append("    : " + ", ".join(ins) + " \\")
+    H.append("    : " + ", ".join(clob) + ")")
+    return H
 
-lines = [
-    "s_mov_b32 s84, %[dA0]", "s_mov_b32 s85, %[dA1]", "s_mov_b32 s87, %[dA3]",
-    "s_mov_b32 s88, %[dB0]", "s_mov_b32 s89, %[dB1]", "s_mov_b32 s91, %[dB3]",
-    "s_cmp_lt_u32 %[koff], %[klim]", "s_cselect_b32 s86, %[dA2], 0", "s_cselect_b32 s90, %[dB2], 0",
-    "s_waitcnt lgkmcnt(0)",
-    "1:",
-]
-for i in range(128):
-    lines.append(mfma(i))
-    lines += sched[i]
 
-outs, ins = [], []
-for mt in range(8):
-    for nt in range(8):
-        outs.append(f'[c{mt}_{nt}] "+a"(acc[{mt}][{nt}])')
-for i in range(8):
-    outs.append(f'[a0_{i}] "+v"(fa[0][{i}])')
-for i in range(8):
-    outs.append(f'[b0_{i}] "+v"(fb[0][{i}])')
-for i in range(8):
-    outs.append(f'[a1_{i}] "=&v"(fa[1][{i}])')
-for i in range(8):
-    outs.append(f'[b1_{i}] "=&v"(fb[1][{i}])')
-for r in ("ra0", "ra1", "rb0", "rb1"):
-    outs.append(f'[{r}] "+v"(g4_{r})')
-for r in ("nk", "koff", "dma"):
-    outs.append(f'[{r}] "+s"(g4_{r})')
-for i in range(8):
-    ins.append(f'[va{i}] "v"(voA[{i}])')
-for i in range(8):
-    ins.append(f'[vb{i}] "v"(voB[{i}])')
-ins.append('[klim] "s"(g4_klim)')
-for i in range(4):
-    ins.append(f'[dA{i}] "s"(g4_dA[{i}])')
-for i in range(4):
-    ins.append(f'[dB{i}] "s"(g4_dB[{i}])')
-clob = ['"memory"', '"scc"'] + [f'"s{i}"' for i in range(84, 92)]
-
-n_dma = sum(1 for l in lines if "buffer_load" in l)
-n_rd = sum(1 for l in lines if "ds_read" in l)
-n_mf = sum(1 for l in lines if "v_mfma" in l)
-assert (n_dma, n_rd, n_mf) == (16, 32, 128), (n_dma, n_rd, n_mf)
-H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} — do not edit.  The K loop of gemm4_kernel as one inline-asm statement:",
-     f"// per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l)} barriers; "
-     f"{len(lines) - 11 - n_mf} other instructions.",
-     "#pragma once",
-     f'#define G4_ASM_VARIANT "{V}"',
-     "#define G4_ASM_LOOP() asm volatile( \\"]
-for l in lines:
-    H.append(f'    "{l}\\n\\t" \\')
-H.append("    : " + ", ".join(outs) + " \\")
-H.append("    : " + ", ".join(ins) + " \\")
-H.append("    : " + ", ".join(clob) + ")")
+H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} --persist {args.persist} — do not edit.",
+     "// The K loop of gemm4_kernel as one inline-asm statement.", "#pragma once", f'#define G4_ASM_VARIANT "{V}"']
+H += build(False)
+if args.persist:
+    H += build(True)
 open(args.out, "w").write("\n".join(H) + "\n")
 print("wrote", args.out, "variant", V)
