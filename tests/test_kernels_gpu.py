@@ -105,8 +105,16 @@ def test_gemm_big_tile_k64_hand_placed_loop(K_):
     close(act, F.silu(g.to(BF).float()).to(BF).float() * u.to(BF).float(), f"k64 fused swiglu K={K_}")
 
 
+@pytest.fixture
+def persist_from_one_round(monkeypatch):
+    """The launcher takes the persistent form from 10 rounds of the CUs up; tests lower that to "more tiles than CUs" (the switch is
+    read per launch) so that small shapes walk several tiles per workgroup."""
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_ROUNDS", "1")
+    monkeypatch.setenv("LMOD_GEMM_PERSIST", "1")
+
+
 @pytest.mark.parametrize("K_", [256, 320, 1024])
-def test_gemm_persistent_tile_walk(K_):
+def test_gemm_persistent_tile_walk(K_, persist_from_one_round):
     # more 256x256 tiles than CUs (18 x 17 = 306 > 256): the persistent four-wave kernel — one workgroup per CU walks several
     # tiles, its K loop's look-ahead runs on into the NEXT tile's operand windows.  Ragged M and N edges (rows / columns past the
     # edge are cut by the buffer descriptors' byte counts on this path), K of 4, 5 and 16 K tiles, second tiles of every parity;
@@ -127,6 +135,28 @@ def test_gemm_persistent_tile_walk(K_):
     gu_ref = K.gemm_nt(a, wgu)
     act, gu = K.gemm_swiglu(a, wgu, want_gu=True)
     assert torch.equal(gu, gu_ref) and torch.equal(act, K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:]))
+    # the one-tile-per-workgroup form of the same launches: bit-identical
+    os.environ["LMOD_GEMM_PERSIST"] = "0"
+    assert torch.equal(got, K_gemm(a, b)) and torch.equal(act, K.gemm_swiglu(a, wgu)[0])
+
+
+def test_fused_qkv_rope_persistent_is_bit_identical(persist_from_one_round):
+    # fused q/k/v projection + bias + RoPE on the persistent kernel (16 x 24 = 384 tiles) against the one-tile-per-workgroup launch
+    # and against GEMM + the separate RoPE kernel
+    T, nh, nkv, Kd = 4000, 16, 16, 512
+    hd, N = 128, (nh + 2 * nkv) * 128
+    x, w, bias = rnd(T, Kd, seed=95), rnd(N, Kd, seed=96), rnd(N, seed=97)
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))
+    fr = torch.arange(4096, device=DEV).float()[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos_t, sin_t = emb.cos().to(BF), emb.sin().to(BF)
+    fused = K.gemm_qkv_rope(x, w, bias, cos_t, sin_t, pos, nh + nkv)
+    os.environ["LMOD_GEMM_PERSIST"] = "0"
+    plain = K.gemm_qkv_rope(x, w, bias, cos_t, sin_t, pos, nh + nkv)
+    ref = K.gemm_nt(x, w, bias=bias)
+    K.rope_(ref, cos_t, sin_t, pos, nh + nkv, hd)
+    assert torch.equal(fused, plain) and torch.equal(fused, ref)
 
 
 def test_gemm_bias_act_f32_accumulate():

@@ -29,6 +29,10 @@ ap.add_argument("--variant", default="b2")
 ap.add_argument("--order", default="mn", help="mn: 8 consecutive MFMAs share the A-side fragment (src1), round 3's order; nm: they share the "
                                           "B-side fragment (src0), the order of hipBLASLt's kernel")
 ap.add_argument("--split-barrier", type=int, default=0, help="1: the wait and its s_barrier one MFMA apart")
+ap.add_argument("--peel", type=int, default=0, help="1: the first K tile is a copy of the loop body whose first k-step multiplies into C = 0 (no 256 "
+                                                    "v_accvgpr_write per output tile).  NOT shipped: round 4 found no way to tell hipcc — as write-only "
+                                                    "'=&a' operands, or '+a' over uninitialised values, the accumulators lose their home registers across "
+                                                    "the persistent tile loop (104 ... 858 spilled VGPRs)")
 ap.add_argument("--persist", type=int, default=0, help="1: also emit G4_ASM_LOOP_P(): when the look-ahead LDS-DMA runs off the end of the K "
                                                        "range it SWITCHES to the next output tile's operand windows (descriptor words dAn / dBn, offset 0) "
                                                        "instead of fetching nothing: a persistent workgroup's operand stream never stops")
@@ -167,14 +171,30 @@ def build(persist):
                 assert any(x.startswith("s_add_u32 m0") for x in sched[i - 1]), i
     lines = ["s_mov_b32 s84, %[dA0]", "s_mov_b32 s85, %[dA1]", "s_mov_b32 s86, %[dA2]", "s_mov_b32 s87, %[dA3]",
              "s_mov_b32 s88, %[dB0]", "s_mov_b32 s89, %[dB1]", "s_mov_b32 s90, %[dB2]", "s_mov_b32 s91, %[dB3]"] + entry + \
-            ["s_waitcnt lgkmcnt(0)", "1:"]
-    n_head = len(lines)
+            ["s_waitcnt lgkmcnt(0)"]
+    if args.peel:
+        # the first K tile, peeled: same placement, k-step 0 accumulates into the constant 0, the closing branch leaves the
+        # statement when it was the only tile and falls into the loop otherwise
+        for i in range(128):
+            m = mfma(i)
+            if i < 64:
+                m = m[:m.rindex(",")] + ", 0"
+            lines.append(m)
+            for x in sched[i]:
+                lines.append("s_cbranch_scc0 2f" if x == "s_cbranch_scc1 1b" else x)
+    lines.append("1:")
+    n_head = len(lines) - (128 if args.peel else 0)
     for i in range(128):
         lines.append(mfma(i))
         lines += sched[i]
+    if args.peel:
+        lines.append("2:")
     outs, ins = [], []
     for mt in range(8):
         for nt in range(8):
+            # "+a" also with the peel (whose first k-step ignores the incoming value): as write-only "=&a" operands hipcc loses the
+            # accumulators' home registers across a persistent tile loop and spills > 100 VGPRs; the C++ side simply leaves acc
+            # uninitialised on this path, so no v_accvgpr_write is emitted either way
             outs.append(f'[c{mt}_{nt}] "+a"(acc[{mt}][{nt}])')
     for i in range(8):
         outs.append(f'[a0_{i}] "+v"(fa[0][{i}])')
@@ -206,10 +226,12 @@ def build(persist):
     n_dma = sum(1 for l in lines if "buffer_load" in l)
     n_rd = sum(1 for l in lines if "ds_read" in l)
     n_mf = sum(1 for l in lines if "v_mfma" in l)
-    assert (n_dma, n_rd, n_mf) == (16, 32, 128), (n_dma, n_rd, n_mf)
+    mul = 2 if args.peel else 1
+    assert (n_dma, n_rd, n_mf) == (16 * mul, 32 * mul, 128 * mul), (n_dma, n_rd, n_mf)
+    n_dma, n_rd, n_mf = n_dma // mul, n_rd // mul, n_mf // mul
     name = "G4_ASM_LOOP_P" if persist else "G4_ASM_LOOP"
-    H = [f"// {name}: per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l)} barriers, "
-         f"{len(lines) - n_head - n_mf} other instructions" + (" (look-ahead switches to the next tile's operand windows)" if persist else ""),
+    H = [f"// {name}: per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l) // mul} barriers, "
+         f"{(len(lines) - n_head - n_mf * mul) // mul} other instructions" + (", first K tile peeled (C = 0)" if args.peel else "") + (" (look-ahead switches to the next tile's operand windows)" if persist else ""),
          f"#define {name}() asm volatile( \\"]
     for l in lines:
         H.append(f'    "{l}\\n\\t" \\')
@@ -219,8 +241,9 @@ def build(persist):
     return H
 
 
-H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} --persist {args.persist} — do not edit.",
-     "// The K loop of gemm4_kernel as one inline-asm statement.", "#pragma once", f'#define G4_ASM_VARIANT "{V}"']
+H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} --peel {args.peel} --persist {args.persist} — do not edit.",
+     "// The K loop of gemm4_kernel as one inline-asm statement.", "#pragma once", f'#define G4_ASM_VARIANT "{V}"',
+     f"#define G4_ASM_PEEL {args.peel}"]
 H += build(False)
 if args.persist:
     H += build(True)
