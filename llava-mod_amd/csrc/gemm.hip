@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #define G4_ASM_HEADER "gemm4_loop_asm.h"
 #endif
 #include G4_ASM_HEADER
+#ifndef G4_ASM_NO_B3
+#include "gemm4_loop_asm_b3.h"      // the three-barrier schedule: +0.8 ... 0.9 % from K = 5504 up, -0.4 % at K = 4096 (profiles/r04_gemm_loop.md)
+#endif
 #endif
 #ifndef G4_ASM_PEEL
 #define G4_ASM_PEEL 0
@@ -1715,6 +1718,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         G4_ASM_LOOP_P();
       } else {
+#ifdef G4_ASM_HAVE_B3
+        if (nkt >= 80) G4_ASM_LOOP_B3();
+        else
+#endif
         G4_ASM_LOOP();
       }
     }

@@ -36,6 +36,7 @@ ap.add_argument("--peel", type=int, default=0, help="1: the first K tile is a co
 ap.add_argument("--persist", type=int, default=0, help="1: also emit G4_ASM_LOOP_P(): when the look-ahead LDS-DMA runs off the end of the K "
                                                        "range it SWITCHES to the next output tile's operand windows (descriptor words dAn / dBn, offset 0) "
                                                        "instead of fetching nothing: a persistent workgroup's operand stream never stops")
+ap.add_argument("--suffix", default="", help="appended to the macro names (a second schedule beside the default one)")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd", "csrc",
                                               "gemm4_loop_asm.h"))
 args = ap.parse_args()
@@ -103,7 +104,7 @@ elif V == "b3":
     for i in [93, 94, 95, 97, 98, 100, 101, 102, 104, 105, 107, 109, 111, 113, 115, 117]:
         sched[i].append(rd(f, "a", 0) if f < 8 else rd(f - 8, "b", 0))
         f += 1
-    for k, a in enumerate([96, 103, 121]):
+    for k, a in enumerate([96, 103, 112]):
         piece(a, 13 + k)                                                # B 5-7
 else:
     raise SystemExit("unknown variant")
@@ -229,7 +230,7 @@ def build(persist):
     mul = 2 if args.peel else 1
     assert (n_dma, n_rd, n_mf) == (16 * mul, 32 * mul, 128 * mul), (n_dma, n_rd, n_mf)
     n_dma, n_rd, n_mf = n_dma // mul, n_rd // mul, n_mf // mul
-    name = "G4_ASM_LOOP_P" if persist else "G4_ASM_LOOP"
+    name = ("G4_ASM_LOOP_P" if persist else "G4_ASM_LOOP") + args.suffix
     H = [f"// {name}: per K tile {n_mf} MFMAs, {n_rd} ds_read_b128, {n_dma} LDS-DMA pieces, {sum(1 for l in lines if 's_barrier' in l) // mul} barriers, "
          f"{(len(lines) - n_head - n_mf * mul) // mul} other instructions" + (", first K tile peeled (C = 0)" if args.peel else "") + (" (look-ahead switches to the next tile's operand windows)" if persist else ""),
          f"#define {name}() asm volatile( \\"]
@@ -242,8 +243,8 @@ def build(persist):
 
 
 H = [f"// GENERATED by tools/gen_gemm4_loop.py --variant {V} --order {args.order} --split-barrier {args.split_barrier} --peel {args.peel} --persist {args.persist} — do not edit.",
-     "// The K loop of gemm4_kernel as one inline-asm statement.", "#pragma once", f'#define G4_ASM_VARIANT "{V}"',
-     f"#define G4_ASM_PEEL {args.peel}"]
+     "// The K loop of gemm4_kernel as one inline-asm statement.", "#pragma once"] + \
+    ([f'#define G4_ASM_VARIANT "{V}"', f"#define G4_ASM_PEEL {args.peel}"] if not args.suffix else [f"#define G4_ASM_HAVE{args.suffix} 1"])
 H += build(False)
 if args.persist:
     H += build(True)
