@@ -185,7 +185,7 @@ def time_optimizer(gb, opt, grad_div, reps=3):
     return round(e0.elapsed_time(e1) / reps, 3)
 
 
-def cpu_config1():
+def cpu_baseline_config1():
     """the oracle's config-1 step (tiny ViT + 2-layer / 4-expert MoE student, 2-layer dense teacher, B = 2, only_kd,
     fp32) on the host cores: 1 warm-up + 3 timed steps."""
     from oracle.decoder import DecoderConfig
@@ -362,7 +362,7 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
     if loss_delta is not None:
         out["loss_delta"] = loss_delta
     try:
-        out["config1"] = cpu_config1()
+        out["config1"] = cpu_baseline_config1()
     except Exception as e:
         out["config1"] = {"error": repr(e)[:200]}
     return out
@@ -611,7 +611,7 @@ def main():
         optimizer_ms = time_optimizer(gb, opt, world * A)
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
         traffic, traffic_note = None, "no committed PMC pass for this shape"
-        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r03_final_gemm_traffic.json", "r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
+        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r04_final_gemm_traffic.json", "r03_final_gemm_traffic.json", "r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
                    if os.path.exists(t)), "")
         if tp:
             tj = json.load(open(tp))
@@ -645,7 +645,7 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128; LMOD_GEMM_WAVES=8: gemm_256_kernel<0>) @ teacher QKV [{gm}x{gn}x{gk}]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128, K loop as one hand-placed asm statement, persistent workgroups from 10 rounds of the CUs up) @ teacher QKV [{gm}x{gn}x{gk}]",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": round(gemm_ms, 4),

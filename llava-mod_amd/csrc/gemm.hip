@@ -1365,7 +1365,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int id = xcd_remap(bid, nwg);
     int bz = id / tpb, split = 0;
     if (MODE == 0 && p.splitk > 1) { split = bz; bz = 0; id -= split * tpb; }
-    const int r = id - bz * tpb;
+    int r = id - bz * tpb;
+    if ((MODE == 6 || MODE == 0) && kvp && !mvp && p.batch > 1 && p.batch <= GEMM_MAX_GROUPS && p.splitk <= 1 && !(tpb & 7)) {
+      // batched weight gradients with a live reduction length per batch (MoE experts): every XCD takes 1/8 of EVERY expert's tiles,
+      // longest reduction first (see gemm_256_kernel: whole experts per XCD ran 2.7x apart with uneven routers)
+      const int tpb8 = tpb >> 3, xcd = bid & 7, k = bid >> 3;
+      const int rnk = k / tpb8;
+      int sel = rnk;
+      for (int e = 0; e < p.batch; ++e) {
+        const int ke = kvp[e];
+        int rank = 0;
+        for (int f = 0; f < p.batch; ++f) {
+          const int kf = kvp[f];
+          rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+        }
+        if (rank == rnk) sel = e;
+      }
+      bz = sel;
+      r = xcd * tpb8 + (k - rnk * tpb8);
+      id = bz * tpb + r;
+    }
     const int GROUP_M = G256_GROUP_M;
     const int grp = r / (GROUP_M * p.tiles_n);
     const int first_m = grp * GROUP_M;
@@ -2196,8 +2215,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   const int r0 = tr * 64 + (lane >> 3) * 8, c0 = tc * 64 + (lane & 7) * 8;
   if (c0 >= C || r0 >= ld_out) return;
   if (r_valid) {       // grouped (MoE capacity slab) use: rows past the live count are never read by the k_valid GEMM —
-    R = min(R, r_valid[bz]);                            // only the 8-column group holding the boundary is zero-filled
-    if (r0 >= ((R + 7) & ~7)) return;
+    R = min(R, r_valid[bz]);                            // the columns up to the next multiple of 64 are zero-filled, so that a
+    if (r0 >= ((R + 63) & ~63)) return;                 // caller may round k_valid up to 64 (whole K tiles: the asm K loop)
   }
   const bf16_t* ip = in + (long long)bz * s_in;
   bf16_t* op = out + (long long)bz * s_out;
@@ -2273,6 +2292,7 @@ static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
     hipLaunchKernelGGL((gemm4_kernel<MODE, false>), dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p0);
   }
 }
+static bool gemm_kv4() { const char* e = getenv("LMOD_GEMM_KV4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 keeps k_valid batches on the 8-wave kernel)
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a44 = false, a46 = false, a47 = false;
@@ -2292,6 +2312,12 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   } else if ((w == 0 || w == 44) && MODE == 0 && p.splitk <= 1 && !p.k_valid && !p.out_f32 && !p.accumulate && p.act != 3) {
     launch_4<7>(p, nwg, stream);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) {   // (not routed: the 8-wave MODE 6 has the two-batch read-modify-write)
+    allow_lds(gemm4_kernel<6>, 2 * G4_STAGE, a46);
+    hipLaunchKernelGGL(gemm4_kernel<6>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+  } else if (MODE == 0 && p.k_valid && !p.m_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok && p.splitk <= 1 &&
+             (p.K & 63) == 0 && (p.N & 3) == 0 && gemm_kv4()) {
+    // MoE expert weight gradients (a live reduction length per expert): the 4-wave kernel, whose K loop is the asm statement for
+    // every expert whose k_valid is a multiple of 64 (the MoE backward rounds it up; the transposes zero-fill to that boundary)
     allow_lds(gemm4_kernel<6>, 2 * G4_STAGE, a46);
     hipLaunchKernelGGL(gemm4_kernel<6>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (MODE == 0 && p.act == 3) {       // the SwiGLU-backward epilogue is its own 8-wave instantiation

@@ -448,9 +448,12 @@ class MoEBlock(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros_like(x)
         dy, dw1, dw2 = K.moe_combine_bwd(dout.contiguous(), y.view(E * C, H), st, H)   # dy: zero rows on empty slots
+        # reduction length of the experts' weight gradients: the routed rows rounded UP to whole 64-row K tiles (the transposes
+        # zero-fill their columns to that boundary), so that the GEMM's K loop is the hand-placed one for every expert
+        kv = torch.clamp((rows + 63) & -64, max=C)
         if sp.down.requires_grad:
             K.gemm_nt(K.transpose(dy.view(E, C, H), r_valid=rows), K.transpose(act, r_valid=rows), out=sp.down.grad_buffer(),
-                      out_f32=True, accumulate=True, k_valid=rows)
+                      out_f32=True, accumulate=True, k_valid=kv)
             sp.down.grad_done()
         if I % 16 == 0:      # grouped down dgrad + SwiGLU backward in one launch (dead rows: zeroed up to the next 8)
             dgu = K.gemm_swiglu_bwd(dy.view(E, C, H), sp.down.transposed(), gu, m_valid=rows, K=H)
@@ -465,7 +468,7 @@ class MoEBlock(torch.autograd.Function):
         K.gemm_nt(dgu, sp.gu.transposed(), out=d_in, m_valid=rows)
         if sp.gu.requires_grad:
             K.gemm_nt(K.transpose(dgu, r_valid=rows), K.transpose(disp.view(E, C, H), r_valid=rows), out=sp.gu.grad_buffer(),
-                      out_f32=True, accumulate=True, k_valid=rows)
+                      out_f32=True, accumulate=True, k_valid=kv)
             sp.gu.grad_done()
         dlogits = K.moe_gate_bwd(st, dw1, dw2, dlaux.contiguous().float() if dlaux is not None else None)
         if sp.wg.requires_grad:

@@ -20,4 +20,7 @@ timeout 600 python tools/bench_kernels.py > $OUT/kernel_microbench.jsonl 2> $OUT
 timeout 300 python tools/bench_gemm.py > $OUT/gemm_shapes.json 2> $OUT/gemm_shapes.err
 timeout 300 python tools/bench_attn.py --bwd-only > $OUT/attn_bench.jsonl 2>/dev/null
 timeout 300 python tools/bench_attn.py >> $OUT/attn_bench.jsonl 2>/dev/null
+timeout 300 python tools/vendor_ab.py > $OUT/vendor_ab.jsonl 2>/dev/null
+timeout 1500 python bench.py --stage dpo --micro-batch 8 > $OUT/bench_dpo.json 2> $OUT/bench_dpo.err; echo "dpo rc=$?"
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_form.json 2>/dev/null
 ls $OUT; tail -c 600 $OUT/bench_default.json
