@@ -665,6 +665,9 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   static int fwd_ver = -1;         // LMOD_ATTN_FWD=1: the round-1 16x16x32 kernel for hd 128 as well (A/B runs)
   if (fwd_ver < 0) { const char* e = getenv("LMOD_ATTN_FWD"); fwd_ver = e ? atoi(e) : 2; }
   if (hd == 128 && (fwd_ver != 1 || cu_seqlens)) { lmod_launch_attn_fwd2(p, causal, stream); return lmod_launch_status(); }
+  // head dim 64 (round 4: the Qwen2-0.5B student, the CLIP tower): the 32x32x16 pipelined kernel with the upper feature half absent;
+  // LMOD_ATTN_FWD=1 keeps the generic 16x16x32 kernel (A/B runs, tests)
+  if (hd == 64 && fwd_ver != 1) { lmod_launch_attn_fwd2(p, causal, stream, 64); return lmod_launch_status(); }
   constexpr int QB = NWAVE * 32;
   const int nqb = (S + QB - 1) / QB;
   const dim3 grid(causal ? (nqb + 1) / 2 : nqb, nh, B);

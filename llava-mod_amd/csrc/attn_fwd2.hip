@@ -267,9 +267,14 @@ __device__ __forceinline__ float half_swap_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool CAUSAL>
+// HD 64 (round 4: the Qwen2-0.5B student of the reference's shells, 14 heads of 64): the SAME tile images, step schedule and register
+// layout with the upper 64 features absent — a K / V row fills the first 8 of its 16 swizzled chunk positions' worth of data, the
+// QK^T k-steps 4-7 and the P·V feature strips 2-3 are not issued (8 + 8 MFMAs per tile instead of 16 + 16), O^T lives in a[0:31].
+// The softmax work per tile is unchanged, so per flop it doubles: this instantiation is VALU-bound by construction.
+template <bool CAUSAL, int HD = 128>
 __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, int h, int b, const int tbase = 0, const bool trace_on = false) {
-  constexpr int QB = 256;
+  static_assert(HD == 128 || HD == 64, "head dim 128 or 64");
+  constexpr int QB = 256, NKS = HD / 16, NDT = HD / 32;
   F2_STAMP(tbase + 0);
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));     // per-lane addresses are re-derived per pass, not hoisted (and spilled) across passes
@@ -292,28 +297,29 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // ---- Q fragments (B operand of S^T): query l31, features ks*16 + hi*8 .. +7
   bf16x8 qf[8];
   {
-    const bf16_t* qp = p.Q + (tok0 + min(q, S - 1)) * p.ldq + h * 128 + hi * 8;
+    const bf16_t* qp = p.Q + (tok0 + min(q, S - 1)) * p.ldq + h * HD + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      qf[ks] = *(const bf16x8*)(qp + ks * 16);
-      if (q >= S) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < NKS) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+      if (q >= S || ks >= NKS) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   acc_zero();
   float mrun = -INFINITY, lrun = 0.f;
 
   // ---- staging: 2 x 16-byte chunks of K and of V per thread and tile
-  const bf16_t* Kb = p.K + tok0 * p.ldk + hk * 128;
-  const bf16_t* Vb = p.V + tok0 * p.ldv + hk * 128;
+  const bf16_t* Kb = p.K + tok0 * p.ldk + hk * HD;
+  const bf16_t* Vb = p.V + tok0 * p.ldv + hk * HD;
   const int srow = tid >> 4, sch = tid & 15;                    // + 32 rows for the second chunk
-  const uint32_t kgo = (uint32_t)(srow * p.ldk + sch * 8) * 2u, vgo = (uint32_t)(srow * p.ldv + sch * 8) * 2u;
-  const uint32_t kgo2 = kgo + (uint32_t)(32 * p.ldk) * 2u, vgo2 = vgo + (uint32_t)(32 * p.ldv) * 2u;
+  const bool no_chunk = (HD == 64) && sch >= 8;                 // HD 64: a row has 8 chunks; the other lanes' loads are out of range (no traffic)
+  const uint32_t kgo = no_chunk ? 0x80000000u : (uint32_t)(srow * p.ldk + sch * 8) * 2u, vgo = no_chunk ? 0x80000000u : (uint32_t)(srow * p.ldv + sch * 8) * 2u;
+  const uint32_t kgo2 = no_chunk ? 0x80000000u : kgo + (uint32_t)(32 * p.ldk) * 2u, vgo2 = no_chunk ? 0x80000000u : vgo + (uint32_t)(32 * p.ldv) * 2u;
   const int kwo = srow * 256 + ((sch ^ (srow & 15)) << 4);      // rows srow and srow+32 share (row & 15) and (row & 3)
   const int vwo = srow * 256 + ((sch ^ ((srow & 3) << 2)) << 4);
   // buffer loads: rows past the end of the sequence are out of range of the descriptor and read as zeros (the tile advance
   // sits in the vector offset: a raw buffer's range check does not see the scalar offset)
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + 128) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + 128) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + HD) * 2), 0x00020000);
   u32x4 kr0, kr1, vr0, vr1;
 #if F2_TOUCH
   uint32_t tk0 = 0, tv0 = 0;
@@ -406,14 +412,15 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     auto kread = [&](const int st) { return *(const bf16x8*)(kb + kaddr[st & 7] + (st >> 3) * 8192); };
     if constexpr (MFMA) {
 #pragma unroll
-      for (int st = 0; st < F2_DEPTH; ++st) kf[st] = kread(st);
+      for (int st = 0; st < F2_DEPTH; ++st) if ((st & 7) < NKS) kf[st] = kread(st);
     }
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
       const int kt = st >> 3, ks = st & 7, nx = st + F2_DEPTH;
       if constexpr (MFMA) {
-        if (F2_ABL != 6) { if (nx < 16) kf[nx % (F2_DEPTH + 1)] = kread(nx); }
+        if (F2_ABL != 6) { if (nx < 16 && (nx & 7) < NKS) kf[nx % (F2_DEPTH + 1)] = kread(nx); }
         if (F2_ABL == 4) { if (ks == 0) { for (int r = 0; r < 16; ++r) s[kt][r] = (float)(r + kt); F2_PIN(s[kt]); } }
+        else if (ks >= NKS) { }                                  // HD 64: features 64-127 do not exist
         else if (kt == 0) { if (ks == 0) qk_mfma<true>(s[0], kf[st % (F2_DEPTH + 1)], qf[ks]); else qk_mfma<false>(s[0], kf[st % (F2_DEPTH + 1)], qf[ks]); }
         else { if (ks == 0) qk_mfma<true>(s[1], kf[st % (F2_DEPTH + 1)], qf[ks]); else qk_mfma<false>(s[1], kf[st % (F2_DEPTH + 1)], qf[ks]); }
       }
@@ -440,7 +447,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     bf16x8 vf[F2_DEPTH + 1];
     if constexpr (PV) {
 #pragma unroll
-      for (int st = 0; st < F2_DEPTH; ++st) vf[st] = lds_tr2(vbp + vaddr[st & 3] + (st >> 2) * 4096);
+      for (int st = 0; st < F2_DEPTH; ++st) if ((st & 3) < NDT) vf[st] = lds_tr2(vbp + vaddr[st & 3] + (st >> 2) * 4096);
     }
     float pm2 = -INFINITY, pm3 = -INFINITY, alpha = 1.f;
     bool resc = false;
@@ -448,8 +455,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     for (int st = 0; st < 16; ++st) {                           // st = kk*4 + dt
       if constexpr (PV) {
         const int kk = st >> 2, dt = st & 3, nx = st + F2_DEPTH;
-        if (F2_ABL != 6) { if (nx < 16) vf[nx % (F2_DEPTH + 1)] = lds_tr2(vbp + vaddr[nx & 3] + (nx >> 2) * 4096); }
+        if (F2_ABL != 6) { if (nx < 16 && (nx & 3) < NDT) vf[nx % (F2_DEPTH + 1)] = lds_tr2(vbp + vaddr[nx & 3] + (nx >> 2) * 4096); }
         if (F2_ABL == 3) { F2_PIN(vf[st % (F2_DEPTH + 1)]); }
+        else if (dt >= NDT) { }                                  // HD 64: feature strips 2, 3 do not exist
         else if (dt == 0) pv_mfma<0>(vf[st % (F2_DEPTH + 1)], pk[kk]);
         else if (dt == 1) pv_mfma<1>(vf[st % (F2_DEPTH + 1)], pk[kk]);
         else if (dt == 2) pv_mfma<2>(vf[st % (F2_DEPTH + 1)], pk[kk]);
@@ -552,7 +560,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   if (q < S) {                                                   // no visible key at all: zeros, lse = -inf
     const float lt = half_swap_sum(lrun + rs);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    bf16_t* op = p.O + (tok0 + q) * p.ldo + h * 128 + hi * 16;
+    bf16_t* op = p.O + (tok0 + q) * p.ldo + h * HD + hi * 16;
     auto store_strip = [&](auto dt_t) {
       constexpr int dt = decltype(dt_t)::value;
       float v[16];
@@ -567,7 +575,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
       *(u32x4*)(op + dt * 32 + 8) = w1;
     };
     store_strip(std::integral_constant<int, 0>{}); store_strip(std::integral_constant<int, 1>{});
-    store_strip(std::integral_constant<int, 2>{}); store_strip(std::integral_constant<int, 3>{});
+    if constexpr (NDT == 4) { store_strip(std::integral_constant<int, 2>{}); store_strip(std::integral_constant<int, 3>{}); }
     if (hi == 0 && p.LSE)
       p.LSE[((long long)b * p.nh + h) * p.S + q] =
           (lt > 0.f) ? mrun * p.scale + __builtin_amdgcn_logf(lt) * 0.6931471805599453f : -INFINITY;
@@ -580,7 +588,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
 // Grid (heads, query blocks, batch): the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so with the
 // head as the FASTEST index every workgroup of head h — all query blocks, all samples — lands on XCD h % 8 and the query
 // blocks of one (batch, head), which read the same K / V rows, share one private L2 (+3 % over the query block fastest).
-template <bool CAUSAL>
+template <bool CAUSAL, int HD = 128>
 __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (CAUSAL) {
@@ -590,31 +598,38 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
     for (int pass = 0; pass < npass; ++pass) {
 #if F2_TRACE
       const bool trace_on = blockIdx.x == 3 && blockIdx.y == F2_TRACE_Y && blockIdx.z == 5;
-      fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z, pass * 60, trace_on);
+      fwd2_block<true, HD>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z, pass * 60, trace_on);
       __syncthreads();
       F2_STAMP(pass * 60 + 59);
 #else
-      fwd2_block<true>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z);
+      fwd2_block<true, HD>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z);
       __syncthreads();
 #endif
     }
   } else {
-    fwd2_block<false>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
+    fwd2_block<false, HD>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
   }
 }
 
-void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream) {
+void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream, int hd) {
   static bool attr = false;
   const int lds = 4 * F2_TB;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nqb = (p.S + 255) / 256;
   const dim3 grid(p.nh, causal ? (nqb + 1) / 2 : nqb, p.B);
-  if (causal) hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(512), lds, stream, p);
-  else hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(512), lds, stream, p);
+  if (hd == 64) {
+    if (causal) hipLaunchKernelGGL((attn_fwd2_kernel<true, 64>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 64>), grid, dim3(512), lds, stream, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_fwd2_kernel<true, 128>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 128>), grid, dim3(512), lds, stream, p);
+  }
 }
 
 #if F2_TRACE

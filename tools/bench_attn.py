@@ -46,6 +46,10 @@ if __name__ == "__main__":
         run(16, 2048, 16, 16, 128, True, True)
         run(8, 2048, 16, 16, 128, False, True)
         sys.exit(0)
+    if "--hd64" in sys.argv:                          # round 4: head dim 64 (Qwen2-0.5B student: 14 heads, 2 KV heads; CLIP tower: 16 heads, S 577)
+        for causal, B, S, nh, nkv in ((True, 16, 2048, 14, 2), (True, 16, 2048, 16, 16), (False, 32, 577, 16, 16), (True, 4, 8192, 14, 2)):
+            run(B, S, nh, nkv, 64, causal, True)
+        sys.exit(0)
     if "--bwd-only" in sys.argv:                      # the backward at the step's shapes (LMOD_ATTN_BWD=1: generic kernels)
         run(16, 2048, 16, 16, 128, True, True)
         run(8, 2048, 16, 16, 128, False, True)
