@@ -23,4 +23,6 @@ timeout 300 python tools/bench_attn.py >> $OUT/attn_bench.jsonl 2>/dev/null
 timeout 300 python tools/vendor_ab.py > $OUT/vendor_ab.jsonl 2>/dev/null
 timeout 1500 python bench.py --stage dpo --micro-batch 8 > $OUT/bench_dpo.json 2> $OUT/bench_dpo.err; echo "dpo rc=$?"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_form.json 2>/dev/null
+timeout 600 python bench.py --experts 8 --no-cpu-baseline > $OUT/bench_e8.json 2>/dev/null
+(cd tools && timeout 300 python bench_attn.py --hd64 > $OUT/attn_hd64.jsonl 2>/dev/null; LMOD_ATTN_FWD=1 timeout 300 python bench_attn.py --hd64 > $OUT/attn_hd64_generic.jsonl 2>/dev/null)
 ls $OUT; tail -c 600 $OUT/bench_default.json
