@@ -1334,6 +1334,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #endif
 #define G4_BOFF (32 * G4_PIECE)
 #define G4_FSTR (G4_PAD ? 128 : 2048)
+// Which tile column (inside a 64-column group) the LDS B row (ntl * 16 + ii) holds; ii = 4 * g + e is the MFMA row a lane group g
+// ends up owning.  Default: 16 contiguous columns per lane (g * 16 + ntl * 4 + e: two 16-byte stores 32 bytes apart from their
+// neighbours').  MODE 7 and MODE 1 (gate and up alike) with G4_SPLIT_COLS: two runs of 8 (columns g * 8 + .. and 32 + g * 8 + ..), so that ONE store instruction writes
+// 64 contiguous, 64-byte aligned bytes per row (4 lanes x 16 bytes) instead of 4 pieces of 16 bytes at a 32-byte stride.
+#ifndef G4_SPLIT_COLS
+#define G4_SPLIT_COLS 1
+#endif
+template <int MODE>
+__device__ __forceinline__ int g4_bcol(const int ntl, const int ii) {
+  if ((MODE == 7 || MODE == 1) && G4_SPLIT_COLS) return (ntl >> 1) * 32 + (ii >> 2) * 8 + (ntl & 1) * 4 + (ii & 3);
+  return (ii >> 2) * 16 + ntl * 4 + (ii & 3);
+}
 struct G4Tile {      // one output tile: coordinates, operand windows, this lane's staging offsets
   int id, bz, split, Mv, Kv, row0, col0, rowsA, rowsB, nkt;
   const bf16_t* Ab; const bf16_t* Bb;
@@ -1430,10 +1442,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       T.voA[j] = (lr < rowsA) ? (uint32_t)((lr * p.lda + cchunk * 8) * 2) : GEMM_OOB;
       const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
       if (MODE != 1) {
-        const int nloc = grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);          // permuted tile column
+        const int nloc = grp64 * 64 + g4_bcol<MODE>(ntl, ii);                       // permuted tile column
         T.voB[j] = (nloc < rowsB) ? (uint32_t)((nloc * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       } else {       // groups 2wc / 2wc+1 = gate / up rows of output columns wc*64 .. +63
-        const int nloc = (grp64 >> 1) * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3);
+        const int nloc = (grp64 >> 1) * 64 + g4_bcol<MODE>(ntl, ii);
         T.voB[j] = (nloc < rowsB) ? (uint32_t)((((long long)(grp64 & 1) * p.N + nloc) * p.ldb + cchunk * 8) * 2) : GEMM_OOB;
       }
     }
@@ -1485,8 +1497,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int lr = (j * 4 + wave) * 8 + (lane >> 3);
       voA[j] = (uint32_t)((lr * p.lda + cchunk * 8) * 2);
       const int grp64 = lr >> 6, rl = lr & 63, ntl = rl >> 4, ii = rl & 15;
-      if (MODE != 1) voB[j] = (uint32_t)(((grp64 * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3)) * p.ldb + cchunk * 8) * 2);
-      else voB[j] = (uint32_t)((((long long)(grp64 & 1) * p.N + (grp64 >> 1) * 64 + (ii >> 2) * 16 + ntl * 4 + (ii & 3)) * p.ldb + cchunk * 8) * 2);
+      if (MODE != 1) voB[j] = (uint32_t)(((grp64 * 64 + g4_bcol<MODE>(ntl, ii)) * p.ldb + cchunk * 8) * 2);
+      else voB[j] = (uint32_t)((((long long)(grp64 & 1) * p.N + (grp64 >> 1) * 64 + g4_bcol<MODE>(ntl, ii)) * p.ldb + cchunk * 8) * 2);
     }
   }
   __amdgpu_buffer_rsrc_t rsA = rsrc_of(Ab, bytesA);
@@ -1769,7 +1781,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---------------------------------------------------------------- epilogue (a lambda: `return` = this tile is done)
   auto epilogue = [&]() {
   if constexpr (MODE == 1) {      // lane: 16 gate columns (acc[mt][0..3]) and the same 16 up columns (acc[mt][4..7])
-    const int cs = col0 + wc * 64 + g * 16;
+    constexpr int H2 = G4_SPLIT_COLS ? 32 : 8;                  // distance between the lane's two 8-column runs (see g4_bcol)
+    const int cs = col0 + wc * 64 + g * (G4_SPLIT_COLS ? 8 : 16);
     bf16_t* Cact = (bf16_t*)p.C + (long long)bz * p.sC;
     bf16_t* Cgu = p.C2 ? (bf16_t*)p.C2 + (long long)bz * p.sC2 : nullptr;
     const int Mz = min((Mv + 7) & ~7, p.M);      // rows Mv..Mz-1 are zero-filled: a k_valid wgrad reads whole 8-row chunks
@@ -1778,17 +1791,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int row = row0 + wr * 128 + mt * 16 + li;
       if (row >= Mz || cs >= p.N) continue;        // N % 8 == 0; a lane's 16 columns may straddle N (second half dropped)
       bf16_t* ap = Cact + (long long)row * p.ldc + cs;
-      const bool hi = (cs + 8 < p.N);
-      if (row >= Mv) { *(u32x4*)ap = (u32x4){0u, 0u, 0u, 0u}; if (hi) *(u32x4*)(ap + 8) = (u32x4){0u, 0u, 0u, 0u}; continue; }
+      const bool hi = (cs + H2 < p.N);
+      if (row >= Mv) { *(u32x4*)ap = (u32x4){0u, 0u, 0u, 0u}; if (hi) *(u32x4*)(ap + H2) = (u32x4){0u, 0u, 0u, 0u}; continue; }
 #pragma unroll
       for (int hx = 0; hx < 2; ++hx) {
         if (hx && !hi) continue;
         float v[16];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v[e] = acc[mt][hx * 2 + (e >> 2)][e & 3]; v[8 + e] = acc[mt][4 + hx * 2 + (e >> 2)][e & 3]; }
-        *(u32x4*)(ap + hx * 8) = swiglu_pairs(v);
+        *(u32x4*)(ap + hx * H2) = swiglu_pairs(v);
         if (Cgu) {
-          bf16_t* gp = Cgu + (long long)row * p.ldc2 + cs + hx * 8;
+          bf16_t* gp = Cgu + (long long)row * p.ldc2 + cs + hx * H2;
           *(u32x4*)gp = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
           *(u32x4*)(gp + p.N) = (u32x4){pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
         }
@@ -1845,7 +1858,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        const int c = col0 + wc * 128 + gq * 64 + g * 16 + x;
+        const int c = (MODE == 7 && G4_SPLIT_COLS) ? col0 + wc * 128 + gq * 64 + (x >> 3) * 32 + g * 8 + (x & 7)
+                                                   : col0 + wc * 128 + gq * 64 + g * 16 + x;
         const float bv = bf2f(p.bias[min(c, p.N - 1)]);
         biav[gq][x] = (c < p.N) ? bv : 0.f;
       }
@@ -1945,7 +1959,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return;
   }
   auto epi_bf16 = [&](const int gq, const int mt) {          // the common case: bf16 C = act(acc + bias), vector stores
-    const int cb = col0 + wc * 128 + gq * 64 + g * 16;
+    constexpr bool SPLIT = (MODE == 7) && G4_SPLIT_COLS;       // v[0..7] | v[8..15]: columns g*8.. and 32 + g*8.. (see g4_bcol)
+    const int cb = col0 + wc * 128 + gq * 64 + (SPLIT ? g * 8 : g * 16);
     const int row = row0 + wr * 128 + mt * 16 + li;
     if (row >= Mv || cb >= p.N) return;
     float v[16];
@@ -1958,12 +1973,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int x = 0; x < 16; ++x) v[x] = act_apply(bfround(v[x]), p.act);
     }
     bf16_t* cp = (bf16_t*)Cb + (long long)row * p.ldc + cb;
-    if ((cb + 16 <= p.N) && p.vec_ok) {
-      *(u32x4*)(cp) = (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-      *(u32x4*)(cp + 8) = (u32x4){pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
-    } else {
+    constexpr int H2 = SPLIT ? 32 : 8;                          // element distance between the lane's two 8-column runs
 #pragma unroll
-      for (int x = 0; x < 16; ++x) if (cb + x < p.N) cp[x] = f2bf(v[x]);
+    for (int h = 0; h < 2; ++h) {
+      const int c0 = cb + h * H2;
+      if ((c0 + 8 <= p.N) && p.vec_ok) {
+        *(u32x4*)(cp + h * H2) = (u32x4){pack2bf(v[8 * h], v[8 * h + 1]), pack2bf(v[8 * h + 2], v[8 * h + 3]),
+                                         pack2bf(v[8 * h + 4], v[8 * h + 5]), pack2bf(v[8 * h + 6], v[8 * h + 7])};
+      } else {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) if (c0 + x < p.N) cp[h * H2 + x] = f2bf(v[8 * h + x]);
+      }
     }
     // persistent form: 64 registers of the next tile's fragments stay live across the epilogue; left free, hipcc converts all 16
     // pieces before the first store (128 packed registers) and spills the fragments around it
