@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #endif
 template <int MODE>
 __device__ __forceinline__ int g4_bcol(const int ntl, const int ii) {
-  if ((MODE == 7 || MODE == 1) && G4_SPLIT_COLS) return (ntl >> 1) * 32 + (ii >> 2) * 8 + (ntl & 1) * 4 + (ii & 3);
+  if ((MODE == 7 || MODE == 1 || MODE == 5) && G4_SPLIT_COLS) return (ntl >> 1) * 32 + (ii >> 2) * 8 + (ntl & 1) * 4 + (ii & 3);
   return (ii >> 2) * 16 + ntl * 4 + (ii & 3);
 }
 struct G4Tile {      // one output tile: coordinates, operand windows, this lane's staging offsets
@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        const int c = (MODE == 7 && G4_SPLIT_COLS) ? col0 + wc * 128 + gq * 64 + (x >> 3) * 32 + g * 8 + (x & 7)
+        const int c = ((MODE == 7 || MODE == 5) && G4_SPLIT_COLS) ? col0 + wc * 128 + gq * 64 + (x >> 3) * 32 + g * 8 + (x & 7)
                                                    : col0 + wc * 128 + gq * 64 + g * 16 + x;
         const float bv = bf2f(p.bias[min(c, p.N - 1)]);
         biav[gq][x] = (c < p.N) ? bv : 0.f;
@@ -1871,7 +1871,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Same roundings as GEMM + bias -> bf16, then rope_kernel.  N % 128 == 0 (host-checked).  Memory order as in the other
     // epilogues: positions first, then cos / sin of two row tiles at a time, issued ahead of the previous two's stores.
     bf16_t* Cb5 = (bf16_t*)p.C + (long long)bz * p.sC;
-    const int cb = col0 + wc * 128 + g * 16;
+    constexpr int GW = G4_SPLIT_COLS ? 8 : 16, H2 = G4_SPLIT_COLS ? 32 : 8;   // the lane's two 8-feature runs: g*GW + 0..7 and + H2 (see g4_bcol)
+    const int cb = col0 + wc * 128 + g * GW;
     if (cb >= p.N) return;
     auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
     auto own = [&](const int mt, const int gq, u32x4& lo, u32x4& hi) {      // bf16(acc + bias): features gq*64 + g*16 + 0..7 | 8..15
@@ -1894,7 +1895,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           own(mt, gq, lo, hi);
           bf16_t* op = Cb5 + (long long)row * p.ldc + cb + gq * 64;
           st_c(op, lo);
-          st_c(op + 8, hi);
+          st_c(op + H2, hi);
         }
       }
       return;
@@ -1906,14 +1907,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto ld = [&](const int b2) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const bf16_t* cp = p.rope_cos + (long long)ps[b2 * 2 + m] * 128 + g * 16;
-        const bf16_t* sp = p.rope_sin + (long long)ps[b2 * 2 + m] * 128 + g * 16;
+        const bf16_t* cp = p.rope_cos + (long long)ps[b2 * 2 + m] * 128 + g * GW;
+        const bf16_t* sp = p.rope_sin + (long long)ps[b2 * 2 + m] * 128 + g * GW;
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
           for (int hx = 0; hx < 2; ++hx) {
-            CC[b2][m][gq][hx] = *(const u32x4*)(cp + gq * 64 + hx * 8);
-            SS[b2][m][gq][hx] = *(const u32x4*)(sp + gq * 64 + hx * 8);
+            CC[b2][m][gq][hx] = *(const u32x4*)(cp + gq * 64 + hx * H2);
+            SS[b2][m][gq][hx] = *(const u32x4*)(sp + gq * 64 + hx * H2);
           }
       }
     };
@@ -1952,7 +1953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (row >= Mv) continue;
         bf16_t* op = Cb5 + (long long)row * p.ldc + cb;
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq) { st_c(op + gq * 64, CC[b2][m][gq][0]); st_c(op + gq * 64 + 8, CC[b2][m][gq][1]); }
+        for (int gq = 0; gq < 2; ++gq) { st_c(op + gq * 64, CC[b2][m][gq][0]); st_c(op + gq * 64 + H2, CC[b2][m][gq][1]); }
       }
     };
     ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); pin(1); ld(2); st(1); cmp(2); pin(2); ld(3); st(2); cmp(3); st(3);

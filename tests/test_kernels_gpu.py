@@ -135,9 +135,13 @@ def test_gemm_persistent_tile_walk(K_, persist_from_one_round):
     gu_ref = K.gemm_nt(a, wgu)
     act, gu = K.gemm_swiglu(a, wgu, want_gu=True)
     assert torch.equal(gu, gu_ref) and torch.equal(act, K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:]))
+    # batched (3 x 9 x 10 = 270 tiles, a tile walk that crosses batch entries) with per-batch weights
+    a3, b3 = rnd(3, 2300, K_, seed=94 + K_), rnd(3, 2560, K_, seed=95 + K_)
+    got3 = K_gemm(a3, b3)
+    close(got3, torch.einsum("bmk,bnk->bmn", a3.float(), b3.float()), f"persistent batched gemm K={K_}")
     # the one-tile-per-workgroup form of the same launches: bit-identical
     os.environ["LMOD_GEMM_PERSIST"] = "0"
-    assert torch.equal(got, K_gemm(a, b)) and torch.equal(act, K.gemm_swiglu(a, wgu)[0])
+    assert torch.equal(got, K_gemm(a, b)) and torch.equal(act, K.gemm_swiglu(a, wgu)[0]) and torch.equal(got3, K_gemm(a3, b3))
 
 
 def test_fused_qkv_rope_persistent_is_bit_identical(persist_from_one_round):
