@@ -2205,6 +2205,229 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }                                                        // tile loop
 }
 
+// =============================================================================================
+// gemm4t_kernel (round 4): the weight-gradient form on the 4-wave tile, WITHOUT transposed copies — fp32 C[b] (M x N) += A[b]^T B[b]
+// with A = dY [K x M] and B = X [K x N] reduction-major, as autograd holds them (K = tokens).  The step used to transpose both
+// operands (transpose_bf16: 2.8 % of GPU time, a quarter of the weight-gradient GEMMs' own time) and run the NT kernel.
+// Tile, wave layout, accumulators and epilogue batching are gemm4_kernel's; the K loop is its own asm statement
+// (gemm4t_loop_asm.h, written by tools/gen_gemm4t_loop.py — LDS image, fragment registers and the walking descriptors are
+// described there).  A reduction-major operand's K edge is a ROW boundary: the descriptors' byte counts cut it exactly, so any K
+// and a per-batch k_valid (MoE routed rows) need no rounding, no zero-filled padding and no per-lane mask.
+// C layout: natural column order — a lane owns 4 contiguous columns per 16-column MFMA tile (columns nt*16 + 4g .. +3 of row li),
+// i.e. one 16-byte fp32 access, four lanes = 64 contiguous bytes per row.
+// SPLIT: deterministic split-K as in gemm_256_kernel (partials to the workspace, the last split to arrive adds them in split order).
+// Host-checked: M % 8 == 0, N % 8 == 0, lda / ldb % 8 == 0, 16-byte aligned operands, every operand window below 2 GiB.
+// =============================================================================================
+#include "gemm4t_loop_asm.h"
+#define G4T_SUB 8448
+#define G4T_PIECE 1056
+#define G4T_OPB 33792
+#define G4T_STAGE 67584
+template <bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4t_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 67584
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tpb = p.tiles_m * p.tiles_n;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  int bz = id / tpb, split = 0;
+  if (SPLIT) { split = bz; bz = 0; id -= split * tpb; }
+  int r = id - bz * tpb;
+  if (!SPLIT && p.k_valid && p.batch > 1 && p.batch <= GEMM_MAX_GROUPS && !(tpb & 7)) {
+    // a live reduction length per batch (MoE experts): every XCD takes 1/8 of EVERY expert's tiles, longest first (see gemm_256_kernel)
+    const int tpb8 = tpb >> 3, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int rnk = k / tpb8;
+    int sel = rnk;
+    for (int e = 0; e < p.batch; ++e) {
+      const int ke = p.k_valid[e];
+      int rank = 0;
+      for (int f = 0; f < p.batch; ++f) {
+        const int kf = p.k_valid[f];
+        rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+      }
+      if (rank == rnk) sel = e;
+    }
+    bz = sel;
+    r = xcd * tpb8 + (k - rnk * tpb8);
+    id = bz * tpb + r;
+  }
+  const int GROUP_M = G256_GROUP_M;
+  const int grp = r / (GROUP_M * p.tiles_n);
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int rr = r - grp * GROUP_M * p.tiles_n;
+  const int tm = first_m + rr % gsz, tn = rr / gsz;
+  int Kv = p.k_valid ? min(p.k_valid[bz], p.K) : p.K;
+  int kbeg = 0;
+  if (SPLIT) {
+    kbeg = split * p.kchunk;
+    Kv = max(0, min(Kv - kbeg, p.kchunk));      // an empty split still arrives at the semaphore with a zero tile
+  }
+  const int row0 = tm * 256, col0 = tn * 256;
+  const int nkt = (Kv + 63) >> 6;
+  if (!SPLIT && nkt == 0) return;
+  const int colsA = min(256, p.M - row0), colsB = min(256, p.N - col0);
+  const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)kbeg * p.lda + row0;
+  const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)kbeg * p.ldb + col0;
+  const uint32_t ksA = (uint32_t)p.lda * 128u, ksB = (uint32_t)p.ldb * 128u;          // bytes per K tile (64 rows)
+  const uint32_t remA = Kv > 0 ? (uint32_t)(((long long)(Kv - 1) * p.lda + colsA) * 2) : 0u;   // live bytes of the window
+  const uint32_t remB = Kv > 0 ? (uint32_t)(((long long)(Kv - 1) * p.ldb + colsB) * 2) : 0u;
+
+  // staging: wave w fills sub-image w (64 columns) of both operands, 8 pieces of 8 k-rows x 128 bytes; piece j, LDS row lane >> 3
+  // holds k-row 8q + u with u = (j & 3) + 4 (row & 1), q = (j >> 2) + 2 (row >> 1)
+  uint32_t voA[8], voB[8];
+  {
+    const int lr = lane >> 3, col = wave * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * ((j >> 2) + 2 * (lr >> 1)) + (j & 3) + 4 * (lr & 1);
+      voA[j] = (col < colsA) ? (uint32_t)((k * p.lda + col) * 2) : GEMM_OOB;
+      voB[j] = (col < colsB) ? (uint32_t)((k * p.ldb + col) * 2) : GEMM_OOB;
+    }
+  }
+  auto rsrc_at = [&](const bf16_t* base, const uint32_t ks, const uint32_t rem, const int t) {     // the window from K tile t on
+    const unsigned long long q = (unsigned long long)base + (unsigned long long)ks * (unsigned)t;
+    const unsigned long long qu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
+    const unsigned long long off = (unsigned long long)ks * (unsigned)t;
+    const uint32_t left = rem > off ? (uint32_t)(rem - off) : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)qu, 0, __builtin_amdgcn_readfirstlane((int)left), 0x00020000);
+  };
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {            // K tiles 0 and 1 -> the two stages (a tile past the end: zero records, zero fill)
+      const __amdgpu_buffer_rsrc_t ra = rsrc_at(Ab, ksA, remA, t), rb = rsrc_at(Bb, ksB, remB, t);
+      char* dst = smem + t * G4T_STAGE + wave * G4T_SUB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + j * G4T_PIECE), 16, voA[j], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(dst + G4T_OPB + j * G4T_PIECE), 16, voB[j], 0, 0, 0);
+      }
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    // this lane's piece of a transposing read: k-row 8 g + (li >> 2) (+4: second half, +32: k-step 1 — immediates), 8 bytes at (li & 3) * 8
+    const uint32_t lbase = (uint32_t)(((li >> 2) + 4 * (g & 1)) * G4T_PIECE + (g >> 1) * 256 + (li & 3) * 8);
+    uint32_t g4_ra1 = lds0 + (2 * wr) * G4T_SUB + lbase, g4_rb1 = lds0 + G4T_OPB + (2 * wc) * G4T_SUB + lbase;      // stage 0 (K tile 0)
+    uint32_t g4_ra0 = g4_ra1 + G4T_STAGE, g4_rb0 = g4_rb1 + G4T_STAGE;                                               // stage 1 (K tile 1)
+    const uint32_t g4_sa = g4_ra0 + g4_ra1, g4_sb = g4_rb0 + g4_rb1;
+    uint32_t g4_dma = __builtin_amdgcn_readfirstlane(lds0 + wave * G4T_SUB);                                         // K tile 2 -> stage 0
+    const uint32_t g4_dsum = 2u * g4_dma + G4T_STAGE;
+    uint32_t g4_nk = __builtin_amdgcn_readfirstlane(nkt);
+    const uint32_t g4_ksA = __builtin_amdgcn_readfirstlane(ksA), g4_ksB = __builtin_amdgcn_readfirstlane(ksB);
+    const unsigned long long pa = (unsigned long long)Ab + 2ull * ksA, pb = (unsigned long long)Bb + 2ull * ksB;
+    const uint32_t g4_dA[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffffu)),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(remA > 2ull * ksA ? remA - 2u * ksA : 0u)), 0x00020000u};
+    const uint32_t g4_dB[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb), (uint32_t)__builtin_amdgcn_readfirstlane((int)((pb >> 32) & 0xffffu)),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(remB > 2ull * ksB ? remB - 2u * ksB : 0u)), 0x00020000u};
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // K tile 0 landed (tile 1's 16 pieces may still fly)
+    asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    G4T_ASM_LOOP();
+    // the asm MFMAs are invisible to the hazard recognizer: let the last accumulator writes retire before reading them
+    asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+  }
+
+  auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+  auto colof = [&](int gq, int x) { return col0 + wc * 128 + gq * 64 + x * 16 + g * 4; };
+  if constexpr (!SPLIT) {
+    // fp32 C += acc: four batches of 4 pieces (16 rows x 64 columns each), every batch's loads issued ahead of the previous one's stores
+    float* Cb = (float*)p.C + (long long)bz * p.sC;
+    f32x4 R[4][4][4];
+    auto ld = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+        const float* cp = Cb + (long long)min(rowof(mt), p.M - 1) * p.ldc;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) R[b][pc][x] = *(const f32x4*)(cp + min(colof(gq, x), p.N - 4));
+      }
+    };
+    auto add = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) R[b][pc][x] += acc[mt][gq * 4 + x];
+      }
+    };
+    auto pin = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) asm volatile("" : "+v"(R[b][pc][0]), "+v"(R[b][pc][1]), "+v"(R[b][pc][2]), "+v"(R[b][pc][3]) : : "memory");
+    };
+    auto st = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const int gq = pc >> 1, mt = b * 2 + (pc & 1), row = rowof(mt);
+        if (row >= p.M) continue;
+        float* cp = Cb + (long long)row * p.ldc;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (colof(gq, x) + 4 <= p.N) *(f32x4*)(cp + colof(gq, x)) = R[b][pc][x];
+      }
+    };
+    ld(0); add(0); pin(0); ld(1); st(0); add(1); pin(1); ld(2); st(1); add(2); pin(2); ld(3); st(2); add(3); st(3);
+  } else {
+    // split-K: partial tile -> workspace, lane-linear, agent-scope stores; the last split to arrive adds all partials in split order
+#pragma unroll
+    for (int mg = 0; mg < 16; ++mg) {
+      const int mt = mg >> 1, gq = mg & 1;
+      float* wp = p.ws + (((long long)split * tpb + id) * 64 + (mt * 2 + gq) * 4) * 1024 + tid * 4;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + x * 1024), "v"(acc[mt][gq * 4 + x]) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = (int*)smem;
+    if (tid == 0)
+      *flag = (__hip_atomic_fetch_add(p.counters + id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.splitk - 1);
+    __syncthreads();
+    if (!*flag) return;
+    float* Cf = (float*)p.C;
+    for (int mg = 0; mg < 16; ++mg) {               // (mt, gq) pairs
+      const int mt = mg >> 1, gq = mg & 1;
+      const int row = rowof(mt);
+      f32x4 o[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const bool live = (row < p.M) && (colof(gq, x) + 4 <= p.N);
+        o[x] = live ? *(f32x4*)(Cf + (long long)row * p.ldc + colof(gq, x)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      for (int s0 = 0; s0 < p.splitk; s0 += 4) {
+        f32x4 part[4][4];
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const float* wp = p.ws + (((long long)min(s0 + ds, p.splitk - 1) * tpb + id) * 64 + mg * 4) * 1024 + tid * 4;
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(part[ds][x]) : "v"(wp + x * 1024) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+          if (s0 + ds < p.splitk) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              asm volatile("" : "+v"(part[ds][x]));
+              o[x] += part[ds][x];
+            }
+          }
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if ((row < p.M) && (colof(gq, x) + 4 <= p.N)) *(f32x4*)(Cf + (long long)row * p.ldc + colof(gq, x)) = o[x];
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 transpose  out[C, ld_out] = in[R, C]^T  (batched).  Each thread transposes an 8x8 block in
 // registers: 8 x 16-byte loads (row-contiguous), 8 x 16-byte stores; lanes are laid out 8 x 8 so
@@ -2526,11 +2749,61 @@ static int wgrad_pick_split(int M, int N, int K, int max_s) {
   return best_s;
 }
 
+// b_kmajor 2: BOTH operands reduction-major (At is dY [K x M], row stride lda; B is X [K x N]) on gemm4t_kernel — no transposed
+// copy of either.  An operand window must stay below 2 GiB (32-bit buffer offsets, out-of-range marker 0x80000000): longer
+// reductions run as several launches over K chunks (the result accumulates either way).
+static bool gemm_tn4() { const char* e = getenv("LMOD_GEMM_TN4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 = the 8-wave TN kernel)
+static void launch_4t(const GemmP& p, long long nwg, hipStream_t stream) {
+  static bool a0 = false, a1 = false;
+  if (p.splitk > 1) {
+    allow_lds(gemm4t_kernel<true>, 2 * G4T_STAGE, a1);
+    hipLaunchKernelGGL(gemm4t_kernel<true>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
+  } else {
+    allow_lds(gemm4t_kernel<false>, 2 * G4T_STAGE, a0);
+    hipLaunchKernelGGL(gemm4t_kernel<false>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
+  }
+}
+static inline int tn4_max_rows(int lda, int ldb) {      // reduction rows per launch that keep both operand windows below 2 GiB
+  const long long ld = lda > ldb ? lda : ldb;
+  const long long rows = (0x7fffffffLL - 1024) / (ld * 2);
+  return (int)(rows > 0x40000000LL ? 0x40000000LL : rows) & ~63;
+}
+static int wgrad_tn4(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     void* workspace, long long workspace_bytes, hipStream_t stream) {
+  if ((M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < M || ldb < N || ldc < N || (ldc & 3)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return LMOD_EINVAL;
+  if (K == 0) return LMOD_OK;
+  const int kmax = tn4_max_rows(lda, ldb);
+  if (kmax < 64) return LMOD_EUNSUPPORTED;
+  long long cap = 0;
+  if (workspace && !((uintptr_t)workspace & 15))
+    cap = (workspace_bytes - (long long)WGRAD_MAX_TILES * 4) / ((long long)((M + 255) / 256) * ((N + 255) / 256) * 262144);
+  for (int k0 = 0; k0 < K; k0 += kmax) {
+    const int kc = (K - k0 < kmax) ? K - k0 : kmax;
+    GemmP p;
+    p.A = (const bf16_t*)A + (long long)k0 * lda; p.B = (const bf16_t*)B + (long long)k0 * ldb; p.C = C; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = kc; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.batch = 1; p.sA = 0; p.sB = 0; p.sC = 0;
+    p.m_valid = nullptr; p.k_valid = nullptr;
+    p.act = 0; p.out_f32 = 1; p.accumulate = 1; p.vec_ok = 1;
+    p.C2 = nullptr; p.ldc2 = 0; p.sC2 = 0;
+    const int s = wgrad_pick_split(M, N, kc, (int)(cap < 1 ? 1 : (cap > 8 ? 8 : cap)));
+    p.splitk = s; p.kchunk = ((kc + s - 1) / s + 63) / 64 * 64;
+    p.counters = (int*)workspace; p.ws = workspace ? (float*)((char*)workspace + (long long)WGRAD_MAX_TILES * 4) : nullptr;
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+    launch_4t(p, (long long)p.tiles_m * p.tiles_n * s, stream);
+    const int st = lmod_launch_status();
+    if (st != LMOD_OK) return st;
+  }
+  return LMOD_OK;
+}
+
 int lmod_gemm_wgrad_bf16_nt(const void* At, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int b_kmajor, void* workspace, long long workspace_bytes, hipStream_t stream) {
   if (M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
   if (M == 0 || N == 0) return LMOD_OK;          // an empty problem dereferences nothing
   if (!At || !B || !C) return LMOD_EINVAL;
+  if (b_kmajor == 2) return wgrad_tn4(At, B, C, M, N, K, lda, ldb, ldc, workspace, workspace_bytes, stream);
   // the workspace bounds the split: WGRAD_MAX_TILES semaphores (16 KiB) + s partial images of 256 KiB per tile
   long long cap = 0;
   if (workspace && !((uintptr_t)workspace & 15))
@@ -2594,6 +2867,10 @@ int lmod_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   const long long nwg = (long long)p.tiles_m * p.tiles_n * batch;
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
+  if (out_f32 && accumulate && gemm_tn4() && K <= tn4_max_rows(lda, ldb)) {      // the fp32 accumulate of the step: the 4-wave asm loop
+    launch_4t(p, nwg, stream);
+    return lmod_launch_status();
+  }
   hipLaunchKernelGGL(gemm_256_kernel<2>, dim3((unsigned)nwg), dim3(512), 8 * G256_SLOT, stream, p);
   return lmod_launch_status();
 }

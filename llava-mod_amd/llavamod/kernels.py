@@ -99,20 +99,28 @@ _WGRAD_WS = {}
 WGRAD_WS_BYTES = 512 << 20
 
 
-def gemm_wgrad(at, b, out, b_kmajor=False):
+def gemm_wgrad(at, b, out, b_kmajor=False, a_kmajor=False):
     """out (fp32 [M, N]) += at[M, K] @ X with X = b[N, K]^T (b_kmajor False) or b[K, N] as autograd holds the layer
-    input (b_kmajor True: no transposed copy of it).  Deterministic split-K when the output has too few tiles to fill
+    input (b_kmajor True: no transposed copy of it).  a_kmajor: `at` is dY [K, M] as autograd holds it too (dW = dY^T X with no
+    transposed copy of either operand: the 4-wave TN kernel).  Deterministic split-K when the output has too few tiles to fill
     the GPU (K = tokens).  One zero-initialised workspace per device, reused by every call on the compute stream."""
     key = at.device.index
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = _WGRAD_WS[key] = torch.zeros(WGRAD_WS_BYTES, device=at.device, dtype=torch.uint8)
-    M, Kd = at.shape
-    if b_kmajor:
-        Kd = min(Kd, b.shape[0])              # at is zero-padded to a multiple of 8 tokens by the transpose
-    N = b.shape[1] if b_kmajor else b.shape[0]
+    if a_kmajor:
+        Kd, M = at.shape
+        Kd = min(Kd, b.shape[0])
+        N = b.shape[1]
+        mode = 2
+    else:
+        M, Kd = at.shape
+        if b_kmajor:
+            Kd = min(Kd, b.shape[0])              # at is zero-padded to a multiple of 8 tokens by the transpose
+        N = b.shape[1] if b_kmajor else b.shape[0]
+        mode = int(b_kmajor)
     call("lmod_gemm_wgrad_bf16_nt", ptr(at), ptr(b), ptr(out), M, N, Kd, at.stride(0), b.stride(0),
-         out.stride(0), int(b_kmajor), ptr(ws), ws.numel())
+         out.stride(0), mode, ptr(ws), ws.numel())
     return out
 
 

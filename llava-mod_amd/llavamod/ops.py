@@ -7,6 +7,8 @@ buffer, see llavamod.engine.GradBuffer); wgrad GEMMs accumulate straight into it
 epilogue and the Function returns None for that input.  That is the layout the RCCL gradient
 exchange and the fused AdamW consume.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -152,6 +154,16 @@ def _ones(n, device):
     return _ONES[key]
 
 
+_ONES_COL = {}
+
+
+def _ones_col(n, device):
+    key = (n, device.index)
+    if key not in _ONES_COL:
+        _ONES_COL[key] = torch.ones((n, 8), device=device, dtype=BF16)
+    return _ONES_COL[key]
+
+
 def linear_fwd(x, fw, act=0, out=None):
     """y = act(x @ W^T + b)."""
     return K.gemm_nt(x, fw.w, bias=fw.b, act=act, out=out)
@@ -175,11 +187,28 @@ def linear_dgrad(dy, fw):
     return K.gemm_nt(dy, wt, M=M, N=N, K=Kd, lda=dy.stride(0), ldb=wt.stride(0))
 
 
+def wgrad_tn():
+    """Weight gradients on the tensors as autograd holds them (dW = dY^T X through the TN kernel's transposing LDS reads) instead of
+    NT GEMMs on transposed copies.  LMOD_WGRAD_TN=0 restores the copies (A/B runs); read per call."""
+    return os.environ.get("LMOD_WGRAD_TN", "1") != "0"
+
+
+def _tn_operand(t):
+    return t.dim() >= 2 and t.stride(-1) == 1 and t.shape[-1] % 8 == 0 and t.stride(-2) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
 def linear_wgrad(dy, x, fw):
     """main_grad += dy^T @ x ; bias main_grad += colsum(dy).
     (Measured and rejected: running the transposes, or the whole weight gradient, on a side stream.  Two GEMMs sharing
     the chip run slower than back to back (-2 %), the transposes alone did not hide under the dgrad GEMM, and with the
     compute stream at high priority and the weight gradients at default priority the step was still 0.4 % slower.)"""
+    if wgrad_tn() and _tn_operand(dy) and _tn_operand(x):
+        K.gemm_wgrad(dy, x, fw.grad_buffer(), a_kmajor=True)
+        if fw.bias_requires_grad:
+            tmp = K.gemm_tn(dy, _ones_col(dy.shape[0], dy.device), out_f32=True)       # [N, 8]; every column = token sum
+            fw.bias_grad_buffer().add_(tmp[:, 0])
+        fw.grad_done()
+        return
     dyt = K.transpose(dy)                     # [N, Tpad]
     xt = K.transpose(x)                       # [K, Tpad]
     K.gemm_wgrad(dyt, xt, fw.grad_buffer())
@@ -451,9 +480,13 @@ class MoEBlock(torch.autograd.Function):
         # reduction length of the experts' weight gradients: the routed rows rounded UP to whole 64-row K tiles (the transposes
         # zero-fill their columns to that boundary), so that the GEMM's K loop is the hand-placed one for every expert
         kv = torch.clamp((rows + 63) & -64, max=C)
+        tn = wgrad_tn()         # reduction-major operands: the live rows are cut exactly by the kernel's descriptors, no copies
         if sp.down.requires_grad:
-            K.gemm_nt(K.transpose(dy.view(E, C, H), r_valid=rows), K.transpose(act, r_valid=rows), out=sp.down.grad_buffer(),
-                      out_f32=True, accumulate=True, k_valid=kv)
+            if tn:
+                K.gemm_tn(dy.view(E, C, H), act, out=sp.down.grad_buffer(), out_f32=True, accumulate=True, k_valid=rows)
+            else:
+                K.gemm_nt(K.transpose(dy.view(E, C, H), r_valid=rows), K.transpose(act, r_valid=rows), out=sp.down.grad_buffer(),
+                          out_f32=True, accumulate=True, k_valid=kv)
             sp.down.grad_done()
         if I % 16 == 0:      # grouped down dgrad + SwiGLU backward in one launch (dead rows: zeroed up to the next 8)
             dgu = K.gemm_swiglu_bwd(dy.view(E, C, H), sp.down.transposed(), gu, m_valid=rows, K=H)
@@ -467,8 +500,11 @@ class MoEBlock(torch.autograd.Function):
         d_in = torch.empty((E, C, H), device=x.device, dtype=BF16)
         K.gemm_nt(dgu, sp.gu.transposed(), out=d_in, m_valid=rows)
         if sp.gu.requires_grad:
-            K.gemm_nt(K.transpose(dgu, r_valid=rows), K.transpose(disp.view(E, C, H), r_valid=rows), out=sp.gu.grad_buffer(),
-                      out_f32=True, accumulate=True, k_valid=kv)
+            if tn:
+                K.gemm_tn(dgu, disp.view(E, C, H), out=sp.gu.grad_buffer(), out_f32=True, accumulate=True, k_valid=rows)
+            else:
+                K.gemm_nt(K.transpose(dgu, r_valid=rows), K.transpose(disp.view(E, C, H), r_valid=rows), out=sp.gu.grad_buffer(),
+                          out_f32=True, accumulate=True, k_valid=kv)
             sp.gu.grad_done()
         dlogits = K.moe_gate_bwd(st, dw1, dw2, dlaux.contiguous().float() if dlaux is not None else None)
         if sp.wg.requires_grad:
@@ -789,15 +825,23 @@ class ExpertFFN(torch.autograd.Function):
         rflat = rows.reshape(-1).contiguous() if rows is not None else None
         if sp.down.requires_grad:
             g = sp.down.grad_buffer()
+            tn = wgrad_tn()
             if El == 1:     # slabs of all source ranks are contiguous: ONE wgrad GEMM over K = ep*C (dead rows are zero)
-                K.gemm_nt(K.transpose(dy.view(ep * C, H)), K.transpose(act.view(ep * C, I)),
-                          out=(g[0] if sp.down.stacked else g), out_f32=True, accumulate=True)
+                if tn:
+                    K.gemm_tn(dy.view(ep * C, H), act.view(ep * C, I), out=(g[0] if sp.down.stacked else g), out_f32=True, accumulate=True)
+                else:
+                    K.gemm_nt(K.transpose(dy.view(ep * C, H)), K.transpose(act.view(ep * C, I)),
+                              out=(g[0] if sp.down.stacked else g), out_f32=True, accumulate=True)
             else:
                 for le in range(El):
                     for src in range(ep):
                         kv = rows[src, le:le + 1].contiguous() if rows is not None else None
-                        K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
-                                  out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+                        if tn:
+                            K.gemm_tn(dy[src, le], act[src, le], out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True,
+                                      k_valid=kv)
+                        else:
+                            K.gemm_nt(K.transpose(dy[src, le]), K.transpose(act[src, le]),
+                                      out=(g[le] if sp.down.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
             sp.down.grad_done()
         if not fused_bwd:
             dgu2 = dgu.view(ep * El * C, 2 * I)
@@ -810,15 +854,23 @@ class ExpertFFN(torch.autograd.Function):
                       strides=(El * C * 2 * I, 0, El * C * H), m_valid=mv)
         if sp.gu.requires_grad:
             g = sp.gu.grad_buffer()
+            tn = wgrad_tn()
             if El == 1:
-                K.gemm_nt(K.transpose(dgu.view(ep * C, 2 * I)), K.transpose(x.view(ep * C, H)),
-                          out=(g[0] if sp.gu.stacked else g), out_f32=True, accumulate=True)
+                if tn:
+                    K.gemm_tn(dgu.view(ep * C, 2 * I), x.view(ep * C, H), out=(g[0] if sp.gu.stacked else g), out_f32=True, accumulate=True)
+                else:
+                    K.gemm_nt(K.transpose(dgu.view(ep * C, 2 * I)), K.transpose(x.view(ep * C, H)),
+                              out=(g[0] if sp.gu.stacked else g), out_f32=True, accumulate=True)
             else:
                 for le in range(El):
                     for src in range(ep):
                         kv = rows[src, le:le + 1].contiguous() if rows is not None else None
-                        K.gemm_nt(K.transpose(dgu[src, le]), K.transpose(x[src, le]),
-                                  out=(g[le] if sp.gu.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
+                        if tn:
+                            K.gemm_tn(dgu[src, le], x[src, le], out=(g[le] if sp.gu.stacked else g), out_f32=True, accumulate=True,
+                                      k_valid=kv)
+                        else:
+                            K.gemm_nt(K.transpose(dgu[src, le]), K.transpose(x[src, le]),
+                                      out=(g[le] if sp.gu.stacked else g), out_f32=True, accumulate=True, k_valid=kv)
             sp.gu.grad_done()
         # dx rows past a slab's live count are not computed; the sender's dispatch backward reads live slots only
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

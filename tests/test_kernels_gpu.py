@@ -301,6 +301,89 @@ def test_gemm_tn_batched_kvalid_and_splitk():
     close(ws.sum(0), a.float().t() @ b.float(), "tn split-K", rtol=1e-4, afrac=1e-5)
 
 
+@pytest.mark.parametrize("Kd,M,N", [(64, 8, 8), (37, 256, 256), (300, 136, 264), (1000, 520, 256), (4096 + 19, 512, 1032), (8192, 768, 512)])
+def test_gemm_tn_accumulate_on_the_four_wave_asm_loop(Kd, M, N, monkeypatch):
+    """fp32 C += A^T B on reduction-major operands takes gemm4t_kernel (4 waves, asm K loop, transposing LDS reads, descriptors cut
+    the K edge at a ROW: any K, no padding).  Against the fp32 product of the same bf16 operands, against the 8-wave TN kernel
+    (LMOD_GEMM_TN4=0), on column sub-views, and a one-hot operand pins the layout (which LDS row / fragment register / output column)."""
+    a_full, b_full = rnd(Kd, M + 16, seed=140), rnd(Kd, N + 8, seed=141)
+    a, b = a_full[:, 8:8 + M], b_full[:, :N]
+    ref = a.float().t() @ b.float()
+    acc = torch.full((M, N), 3.0, device=DEV, dtype=torch.float32)
+    K.gemm_tn(a, b, out=acc, accumulate=True)
+    close(acc, ref + 3.0, f"tn4 accumulate {Kd}x{M}x{N}", rtol=1e-4, afrac=1e-5)
+    monkeypatch.setenv("LMOD_GEMM_TN4", "0")
+    old = torch.full((M, N), 3.0, device=DEV, dtype=torch.float32)
+    K.gemm_tn(a, b, out=old, accumulate=True)
+    monkeypatch.delenv("LMOD_GEMM_TN4")
+    close(acc, old, "tn4 vs the 8-wave TN kernel", rtol=1e-4, afrac=1e-5)
+    # exact layout check: A = one-hot rows -> C[m] = B[k(m)]; a permutation so that a swapped k or m shows
+    n1 = min(Kd, M)
+    perm = torch.randperm(n1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    eye = torch.zeros(Kd, M, device=DEV, dtype=BF)
+    eye[perm, torch.arange(n1, device=DEV)] = 1
+    got = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    K.gemm_tn(eye, b, out=got, accumulate=True)
+    assert torch.equal(got[:n1], b[perm].float()), "layout"
+    assert got[n1:].abs().max().item() == 0 if n1 < M else True
+    # rows past K (garbage, even NaN) are never read: the descriptors end at the last live row
+    big_a, big_b = torch.full((Kd + 64, M), float("nan"), device=DEV, dtype=BF), torch.full((Kd + 64, N), float("nan"), device=DEV, dtype=BF)
+    big_a[:Kd], big_b[:Kd] = a, b
+    cut = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    K.gemm_tn(big_a, big_b, out=cut, accumulate=True, K=Kd)
+    close(cut, ref, "rows past K must not be read", rtol=1e-4, afrac=1e-5)
+
+
+def test_gemm_tn4_batched_kvalid_exact_rows():
+    """MoE expert weight gradients without transposed copies: a live row count per expert (zero, ragged, full), garbage behind it."""
+    for (E, C, H, I, kvl) in [(4, 200, 136, 264, [200, 0, 77, 130]), (4, 1024, 512, 256, [1024, 3, 640, 511]), (3, 512, 2048, 256, [512, 64, 200])]:
+        dy, x = rnd(E, C, I, seed=142), rnd(E, C, H, seed=143)
+        kv = torch.tensor(kvl, device=DEV, dtype=torch.int32)
+        for e in range(E):
+            dy[e, kvl[e]:] = float("nan")
+            x[e, kvl[e]:] = float("inf")
+        dw = torch.full((E, I, H), 1.0, device=DEV, dtype=torch.float32)
+        K.gemm_tn(dy, x, out=dw, accumulate=True, k_valid=kv)
+        for e in range(E):
+            n = kvl[e]
+            close(dw[e], dy[e, :n].float().t() @ x[e, :n].float() + 1.0, f"tn4 k_valid e{e} ({kvl})", rtol=1e-4, afrac=1e-5)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(512, 512, 8192), (2048, 256, 4096 + 64), (264, 272, 5000), (128, 64, 512), (6144, 2048, 4096)])
+def test_gemm_wgrad_tn_splitk_deterministic(M, N, Kd):
+    """dW += dY^T X with both operands as autograd holds them (a_kmajor: lmod_gemm_wgrad_bf16_nt mode 2), deterministic split-K
+    through the tile semaphores; the same numbers as the NT kernel on transposed copies (same products, same order inside a K tile)."""
+    dy, x = rnd(Kd, M, seed=150), rnd(Kd, N, seed=151)
+    ref = dy.float().t() @ x.float()
+    outs = []
+    for _ in range(3):
+        g = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+        K.gemm_wgrad(dy, x, g, a_kmajor=True)
+        outs.append(g)
+    close(outs[0], ref + 0.5, f"wgrad tn {M}x{N}x{Kd}", rtol=1e-4, afrac=1e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split-K must not depend on arrival order"
+    K.gemm_wgrad(dy, x, outs[0], a_kmajor=True)
+    close(outs[0], 2 * ref + 0.5, "wgrad tn accumulates", rtol=1e-4, afrac=1e-5)
+    nt = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+    K.gemm_wgrad(K.transpose(dy), K.transpose(x), nt)
+    close(outs[1], nt, "wgrad tn vs NT on transposed copies", rtol=1e-4, afrac=1e-5)
+
+
+def test_gemm_wgrad_tn_long_window_runs_in_k_chunks():
+    """An operand window past 2 GiB (the lm_head's dY: [loss rows, vocab]) is walked in K chunks of whole launches."""
+    Kd, M, N = 1536, 151936 * 5, 8            # row pitch 1.5 MB: 2 GiB / pitch = 1413 rows -> two launches
+    dy = torch.zeros(Kd, M, device=DEV, dtype=BF)
+    x = rnd(Kd, N, seed=152)
+    cols = torch.tensor([0, 77, 4095, M - 1], device=DEV)
+    dy[:, cols] = rnd(Kd, 4, seed=153)
+    g = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    K.gemm_wgrad(dy, x, g, a_kmajor=True)
+    close(g[cols], dy[:, cols].float().t() @ x.float(), "k-chunked wgrad", rtol=1e-4, afrac=1e-5)
+    dead = torch.ones(M, device=DEV, dtype=torch.bool)
+    dead[cols] = False
+    assert g[dead].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("M,N,Kd", [(512, 512, 8192), (2048, 256, 4096 + 64), (264, 272, 5000 // 8 * 8), (128, 64, 512)])
 def test_gemm_wgrad_splitk_deterministic(M, N, Kd):
     # fp32 accumulate with split-K through the tile semaphores: right answer, and bit-identical run to run
