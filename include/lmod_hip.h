@@ -66,6 +66,10 @@ int lmod_gemm_swiglu_bwd_bf16(const void* A, const void* Bt, const void* gu, voi
  * weights, dW = dY^T X; the reference gets this from autograd + DeepSpeed's fp32 gradient accumulation).
  * At = dY^T [M x K] (K-contiguous).  X: b_kmajor 0 -> Bt [N x K] (K-contiguous); b_kmajor 1 -> the layer input as
  * autograd holds it, [K x N] with row stride ldb (read through transposing LDS reads, no transposed copy).
+ * b_kmajor 2 -> BOTH operands as autograd holds them: At is dY [K x M] (row stride lda), B is X [K x N]; no transposed
+ * copy of either (the step's path: grad_output.t() @ input of nn.Linear's backward, reference linears as in
+ * lmod_gemm_bf16_nt).  Mode 2 requires M % 8 == 0, N % 8 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned
+ * pointers; any K; operand windows past 2 GiB are walked in K chunks.
  * Few-tile outputs use deterministic split-K.  workspace: 16-byte aligned device memory, zeroed ONCE by the caller,
  * used by one stream at a time: 16 KiB of tile semaphores (self-resetting) + up to 8 partial images of 256 KiB per
  * 256x256 tile; its size bounds the split (NULL: no split).  The last split to arrive adds all partials in split
