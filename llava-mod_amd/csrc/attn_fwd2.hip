@@ -51,6 +51,11 @@ __device__ unsigned long long f2_trace_buf[8 * 128];
 #ifndef F2_SCHED
 #define F2_SCHED 1
 #endif
+#ifndef F2_PK
+#define F2_PK 0                     // 1: packed fp32 math in the softmax slices (v_pk_fma_f32 / v_pk_add_f32: 224 each instead of 448 scalar
+#endif                              //    FMAs / adds).  Measured round 4: 752 -> 505 TF (B16 S2048 causal) — the even-aligned register pairs cost
+#if 0                               //    hipcc 34-39 spilled VGPRs and compiler moves through a[0:63] (the ISA audit in tests/test_abi.py fails)
+#endif
 #ifndef F2_TOUCH
 #define F2_TOUCH 0                  // > 0: L2 touch of the K / V tiles this many iterations ahead of their register loads
 #endif
@@ -361,10 +366,24 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   for (int kk = 0; kk < 4; ++kk) pk[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 
   float nmc = 0.f, rs = 0.f;           // -max*c of the tile being exponentiated; row-sum partial of the running iteration
+#if F2_PK
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 rs2 = {0.f, 0.f};
+#endif
   float pm0 = -INFINITY, pm1 = -INFINITY;
   // exp2 of 2 scores of key half KT (elements e0, e0+1 of s[KT]) against nmc; packs a finished group of 8 into pk[2*KT + g]
   auto exp_pair = [&](auto kt_t, const int e0) {
     constexpr int KT = decltype(kt_t)::value;
+#if F2_PK
+    {   // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of work per issue slot): the scale-and-shift of both scores in
+        // one instruction, the row sum as two partials (rs2) in one
+      const f32x2 t = __builtin_elementwise_fma((f32x2){s[KT][e0], s[KT][e0 + 1]}, (f32x2){c, c}, (f32x2){nmc, nmc});
+      f32x2 pv = {(F2_ABL == 2) ? s[KT][e0] : __builtin_amdgcn_exp2f(t[0]), (F2_ABL == 2) ? s[KT][e0 + 1] : __builtin_amdgcn_exp2f(t[1])};
+      s[KT][e0] = pv[0]; s[KT][e0 + 1] = pv[1];
+      if (F2_ABL != 7) rs2 += pv;
+    }
+    F2_PIN(rs2);
+#else
 #pragma unroll
     for (int e = e0; e < e0 + 2; ++e) {
       const float pv = (F2_ABL == 2) ? s[KT][e] : __builtin_amdgcn_exp2f(__builtin_fmaf(s[KT][e], c, nmc));
@@ -372,6 +391,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
       if (F2_ABL != 7) rs += pv;                               // ablation 7: no row sum
     }
     F2_PIN(rs);
+#endif
     if ((e0 & 7) == 6) {
       const int rb = e0 - 6;
       u32x4 w = {pack2bf(s[KT][rb], s[KT][rb + 1]), pack2bf(s[KT][rb + 2], s[KT][rb + 3]),
@@ -473,6 +493,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
           const float mnew = resc ? fmaxf(mrun, mx) : mrun;
           const float a0 = __builtin_amdgcn_exp2f((mrun - mnew) * c);              // NaN only when both are -inf
           alpha = (mnew == mrun) ? 1.f : a0;
+#if F2_PK
+          rs = rs2[0] + rs2[1]; rs2 = (f32x2){0.f, 0.f};
+#endif
           lrun = (lrun + rs) * alpha;                            // rs: every probability of the tiles before j
           rs = 0.f;
           mrun = mnew;
@@ -558,6 +581,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // ---- epilogue: lane (query l31, half hi) holds features dt*32 + hi*16 + r of its query
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // last asm MFMA -> accumulator reads
   if (q < S) {                                                   // no visible key at all: zeros, lse = -inf
+#if F2_PK
+    rs = rs2[0] + rs2[1];
+#endif
     const float lt = half_swap_sum(lrun + rs);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     bf16_t* op = p.O + (tok0 + q) * p.ldo + h * HD + hi * 16;
