@@ -2513,13 +2513,16 @@ static int gemm_cus() {
   return n;
 }
 static bool gemm_persist(const GemmP& p, long long nwg) {
-  // measured (profiles/r04_gemm_loop.md): +1.5 % at 24 rounds of the CUs (teacher QKV), +4.8 % at 12 rounds with K 2048, level or
-  // slightly behind at 4 - 8 rounds, where a static tile-to-CU assignment loses what the hardware dispatcher's dynamic one balances.
+  // measured (profiles/r04_gemm_loop.md): +1.5 % at 24 rounds of the CUs (teacher QKV), +4.8 % at 12 rounds with K 2048.  The first
+  // threshold was 10 rounds (4 - 8 rounds measured level on the build of that day); on the final build (split-column stores) the
+  // persistent form is ahead from 4 rounds up — +14 % at [32768 x 2048 x 2048] (4 rounds, 32 K tiles per output tile: the
+  // prologue / epilogue share is largest there), +3.9 % at 8 rounds with K 4096, +1 % elsewhere — and in the step 10 -> 4 is
+  // +0.8 ... 1.0 % on two boxes (24.18 -> 24.42, 25.08 -> 25.30 samples/s); 3 and 2 are level with 4.
   // The two switches are read per launch (a getenv is nothing beside a launch) so that one test process can run both forms.
   const char* e = getenv("LMOD_GEMM_PERSIST");
   const int on = e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT;
   const char* r = getenv("LMOD_GEMM_PERSIST_ROUNDS");
-  const int min_rounds = r ? atoi(r) : 10;
+  const int min_rounds = r ? atoi(r) : 4;
   return on && G4_ASM && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus() && nwg >= (long long)min_rounds * gemm_cus() &&
          (p.K & 63) == 0 && p.K >= 256;
 }
