@@ -2554,8 +2554,8 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3) {     // (in-step: 1177 us per launch against 1124 us for
-    allow_lds(gemm4_kernel<4>, 2 * G4_STAGE, a44);                                       //  the 8-wave kernel's two-batch epilogue: not routed)
-    hipLaunchKernelGGL(gemm4_kernel<4>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
+    (void)a44;                                                                          //  the 8-wave kernel's two-batch epilogue: not routed)
+    launch_4<4>(p, nwg, stream);                                                        // persistent when the launch qualifies (dense layers)
   } else if ((w == 0 || w == 44) && MODE == 0 && p.splitk <= 1 && !p.k_valid && !p.out_f32 && !p.accumulate && p.act != 3) {
     launch_4<7>(p, nwg, stream);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) {   // (not routed: the 8-wave MODE 6 has the two-batch read-modify-write)
