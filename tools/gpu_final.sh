@@ -14,6 +14,9 @@ SQ1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 -d $OUT/gemm_sq -o a --output-format csv -- python $OLDPWD/tools/gemm_one.py > $OUT/gemm_sq.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/gemm_fetch -o a --output-format csv -- python $OLDPWD/tools/gemm_one.py > $OUT/gemm_fetch.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/gemm_write -o a --output-format csv -- python $OLDPWD/tools/gemm_one.py > $OUT/gemm_write.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 -d $OUT/wgrad_sq -o a --output-format csv -- python $OLDPWD/tools/wgrad_one.py > $OUT/wgrad_sq.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/wgrad_fetch -o a --output-format csv -- python $OLDPWD/tools/wgrad_one.py > $OUT/wgrad_fetch.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/wgrad_write -o a --output-format csv -- python $OLDPWD/tools/wgrad_one.py > $OUT/wgrad_write.log 2>&1)
 (cd /tmp && A1_B=16 timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 -d $OUT/attn_sq -o a --output-format csv -- python $OLDPWD/tools/attn_one.py bwd > $OUT/attn_sq.log 2>&1)
 (cd /tmp && A1_B=16 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/attn_inst -o a --output-format csv -- python $OLDPWD/tools/attn_one.py bwd > $OUT/attn_inst.log 2>&1)
 timeout 600 python tools/bench_kernels.py > $OUT/kernel_microbench.jsonl 2> $OUT/kernel_microbench.err

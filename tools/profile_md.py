@@ -125,6 +125,25 @@ def pmc_md():
             "~2 TB/s of fabric traffic under an MFMA-bound kernel, not HBM over-fetch.",
             "", "| counter | per dispatch |", "|---|---|"]
     out += [f"| {a} | {b:.4g} |" for a, b in sorted(c.items())]
+    if glob.glob(f"{src}/wgrad_sq/*counter_collection.csv"):
+        t = pmc("wgrad_sq"); tf = pmc("wgrad_fetch"); tw = pmc("wgrad_write")
+        tk = next(x for x in t if "gemm4t_kernel" in x)
+        c, us = t[tk]
+        live = 9000 + 12500 + 20036 + 24000
+        flop = 2.0 * live * 11008 * 2048
+        algo = (live * (11008 + 2048) * 2 + 4 * 11008 * 2048 * 8)
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        out += ["", "## `gemm4t_kernel<false>` (weight gradients on reduction-major operands) at the MoE gate+up shape: 4 experts x [11008 x 2048], "
+                f"{live} live rows (`python tools/wgrad_one.py`)", "",
+                f"* duration under the counter passes: {us:.0f} us ({flop / us / 1e6:.0f} TFLOP/s); effective clock **{cyc / us / 1e3:.2f} GHz**",
+                f"* MFMA pipe busy: **{c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.1f} %** of the cycles the chip actually ran",
+                f"* LDS: SQ_LDS_BANK_CONFLICT = {c['SQ_LDS_BANK_CONFLICT']:.0f} against SQ_LDS_IDX_ACTIVE = {c['SQ_LDS_IDX_ACTIVE']:.4g} "
+                f"(the padded, XOR-free image; `tools/probe/gemm4t_layout.py` predicts zero), LDS active {c['SQ_LDS_IDX_ACTIVE'] / 256 / cyc * 100:.0f} % of CU cycles "
+                "(twice the instructions of the NT kernel's `ds_read_b128` for the same bytes)",
+                f"* memory side: FETCH_SIZE x 2 = **{2 * tf[tk][0]['FETCH_SIZE'] / 1e6:.2f} GB**, WRITE_SIZE **{tw[tk][0]['WRITE_SIZE'] / 1e6:.2f} GB** per launch; "
+                f"algorithmic bytes (live rows of dY and X once, fp32 C read + written) {algo / 1e9:.2f} GB",
+                "", "| counter | per dispatch |", "|---|---|"]
+        out += [f"| {a_} | {b_:.4g} |" for a_, b_ in sorted(c.items())]
     a = pmc("attn_sq")
     out += ["", "## attention kernels, B 16, S 2048, 16 heads, hd 128, causal (`A1_B=16 python tools/attn_one.py bwd`; first launches, "
             "clock not yet settled: durations are longer than in the micro-benchmarks)", "",
