@@ -35,6 +35,15 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, i
                       int ldc, int batch, long long strideA, long long strideB, long long strideC, const int* m_valid,
                       const int* k_valid, int act, int out_f32, int accumulate, hipStream_t stream);
 
+/* C[M x N] = bf16(res + bf16(A W^T)): a bias-free projection whose output joins the residual stream — the decoder layer's
+ * hidden_states = residual + self_attn(...) / residual + mlp(...) (qwen2/modeling_qwen2.py:757-775; MoE layer:
+ * llava_qwen2_moe.py:143-167) with the add in the GEMM epilogue.  Same roundings as lmod_gemm_bf16_nt followed by the residual
+ * path of lmod_rmsnorm_fwd (bit-identical); the norm that follows then reads one tensor and writes one.  Only shapes that
+ * lmod_gemm_bf16_nt runs on the 4-wave 256-tile kernel (M >= 512, N >= 256, enough tiles): others return LMOD_EUNSUPPORTED and the
+ * caller keeps the two-step form.  N % 8 == 0, ldc / ldr % 8 == 0, 16-byte aligned pointers, C != res, bias must be NULL. */
+int lmod_gemm_bf16_nt_res(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
+                          int ldw, int ldc, int ldr, hipStream_t stream);
+
 /* Fused q/k/v projection + rotary embedding: C[M x N] = rope(A W^T + bias), W = [Wq; Wk; Wv] stored as ONE [N x K] matrix.
  * Replaces `self.q_proj / k_proj / v_proj` followed by `apply_rotary_pos_emb` (qwen2/modeling_qwen2.py:262-264, :146-171;
  * tables :119-134) in ONE launch: heads are 128 wide, columns [0, rope_cols) hold the q and k heads and are rotated in the GEMM

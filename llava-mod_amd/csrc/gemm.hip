@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(GemmP p) {
 #endif
 template <int MODE>
 __device__ __forceinline__ int g4_bcol(const int ntl, const int ii) {
-  if ((MODE == 7 || MODE == 1 || MODE == 5) && G4_SPLIT_COLS) return (ntl >> 1) * 32 + (ii >> 2) * 8 + (ntl & 1) * 4 + (ii & 3);
+  if ((MODE == 7 || MODE == 8 || MODE == 1 || MODE == 5) && G4_SPLIT_COLS) return (ntl >> 1) * 32 + (ii >> 2) * 8 + (ntl & 1) * 4 + (ii & 3);
   return (ii >> 2) * 16 + ntl * 4 + (ii & 3);
 }
 struct G4Tile {      // one output tile: coordinates, operand windows, this lane's staging offsets
@@ -1853,12 +1853,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
     for (int x = 0; x < 16; ++x) biav[gq][x] = 0.f;
-  if (p.bias) {             // clamped, unconditional loads: 32 in flight, one wait (a per-element condition made each its own round trip)
+  if (MODE != 8 && p.bias) {       // (MODE 8: no bias — the decoder's o / down projections have none; host-checked)             // clamped, unconditional loads: 32 in flight, one wait (a per-element condition made each its own round trip)
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        const int c = ((MODE == 7 || MODE == 5) && G4_SPLIT_COLS) ? col0 + wc * 128 + gq * 64 + (x >> 3) * 32 + g * 8 + (x & 7)
+        const int c = ((MODE == 7 || MODE == 8 || MODE == 5) && G4_SPLIT_COLS) ? col0 + wc * 128 + gq * 64 + (x >> 3) * 32 + g * 8 + (x & 7)
                                                    : col0 + wc * 128 + gq * 64 + g * 16 + x;
         const float bv = bf2f(p.bias[min(c, p.N - 1)]);
         biav[gq][x] = (c < p.N) ? bv : 0.f;
@@ -2099,6 +2099,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(op + p.N + hx * 8) = (u32x4){0u, 0u, 0u, 0u}; }
       }
     }
+  } else if constexpr (MODE == 8) {
+    // bf16 C = bf16(res + bf16(acc)): the decoder layer's residual add (qwen2/modeling_qwen2.py:757-775: hidden = residual +
+    // o_proj(...) / + mlp(...)) in the epilogue of the o / down projection — the roundings of GEMM -> bf16, then the add of
+    // rmsnorm_fwd_kernel's residual path (rowops.hip), so the result is that pair's, bit for bit, and the norm that follows reads
+    // ONE tensor instead of two and writes one instead of two.  res = p.C2 (row stride ldc2), N % 8 == 0, 16-byte aligned rows
+    // (host-checked).  Memory order as in MODE 6, in batches of one row tile (2 pieces: four at a time spilled beside the 256 accumulators): each
+    // batch's residual loads are issued ahead of the previous batch's stores.  Columns: the split layout of MODE 7 (runs g*8 .. +7 and 32 + g*8 .. +7 of every 64-column group).
+    constexpr int GW = G4_SPLIT_COLS ? 8 : 16, H2 = G4_SPLIT_COLS ? 32 : 8;
+    auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
+    auto colof = [&](int gq) { return col0 + wc * 128 + gq * 64 + g * GW; };
+    const bf16_t* Rb = (const bf16_t*)p.C2 + (long long)bz * p.sC2;
+    u32x4 RR[8][2][2];                               // eight batches of 2 pieces (one row tile, both 64-column groups): 16 registers each
+    auto ld = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int gq = pc, mt = b;
+        const bf16_t* rp = Rb + (long long)min(rowof(mt), p.M - 1) * p.ldc2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) RR[b][pc][h] = *(const u32x4*)(rp + min(colof(gq) + h * H2, p.N - 8));
+      }
+    };
+    auto cmp = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int gq = pc, mt = b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = 2 * k;
+            const uint32_t d = pack2bf(acc[mt][gq * 4 + h * 2 + (e >> 2)][e & 3], acc[mt][gq * 4 + h * 2 + ((e + 1) >> 2)][(e + 1) & 3]);
+            const uint32_t r = RR[b][pc][h][k];
+            o[k] = pack2bf(bflo(d) + bflo(r), bfhi(d) + bfhi(r));
+          }
+          RR[b][pc][h] = o;
+        }
+      }
+    };
+    auto pin = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(RR[b][pc][0]), "+v"(RR[b][pc][1]) : : "memory");
+    };
+    auto st = [&](const int b) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int gq = pc, mt = b, row = rowof(mt);
+        if (row >= Mv) continue;
+        bf16_t* cp = (bf16_t*)Cb + (long long)row * p.ldc + colof(gq);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (colof(gq) + h * H2 + 8 <= p.N) st_c(cp + h * H2, RR[b][pc][h]);
+      }
+    };
+    ld(0); cmp(0); pin(0);
+#pragma unroll
+    for (int b = 1; b < 8; ++b) { ld(b); st(b - 1); cmp(b); pin(b); }
+    st(7);
   } else if constexpr (MODE == 6) {
     // fp32 C += acc (no bias / act / split; C and ldc 16-byte aligned, N % 16 == 0 not required: whole 4-column groups), four
     // batches of 4 pieces as above
@@ -2626,6 +2683,37 @@ int lmod_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias,
   if (nwg > 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   if (big) launch_256<0>(p, nwg, stream);
   else hipLaunchKernelGGL(gemm_nt_128, dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  return lmod_launch_status();
+}
+
+// C[M, N] = bf16(res + bf16(A W^T)): a projection (no bias) whose output is added to the residual stream (the decoder layer's
+// hidden = residual + o_proj(attn) / + down_proj(mlp), qwen2/modeling_qwen2.py:757-775) with the add in the GEMM epilogue — what
+// lmod_gemm_bf16_nt followed by the residual path of lmod_rmsnorm_fwd computes, bit for bit, one pass over [M, N] less on each side.
+// Only on the 4-wave 256-tile kernel: shapes that lmod_gemm_bf16_nt would send elsewhere return LMOD_EUNSUPPORTED (the caller keeps
+// the two-step form; kernels.gemm_res_fusable mirrors the test).  N % 8 == 0, C / res rows 16-byte aligned, C != res.
+static bool gemm_res_shape_ok(int M, int N, int K, int lda, int ldb) {
+  const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool big = (M >= 512 && N >= 256 && (t256 >= 160 || (t256 >= 96 && K >= 8192))) &&
+                   ((long long)((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) <= (long long)M * N * 115 / 100 + 65536);
+  return big && (long long)255 * lda * 2 + (long long)K * 2 < 0x7fffffffLL && (long long)255 * ldb * 2 + (long long)K * 2 < 0x7fffffffLL &&
+         gemm_waves() == 0 && G4_ASM;
+}
+int lmod_gemm_bf16_nt_res(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
+                          int ldw, int ldc, int ldr, hipStream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return LMOD_EINVAL;
+  if (M == 0 || N == 0) return LMOD_OK;
+  if (!A || !W || !C || !res || C == res || bias) return LMOD_EINVAL;        // (no bias on this path: the decoder's o / down projections have none)
+  if ((K & 7) || (lda & 7) || (ldw & 7) || lda < K || ldw < K || ldc < N || ldr < N || (ldc & 7) || (ldr & 7) || (N & 7)) return LMOD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15) || ((uintptr_t)res & 15)) return LMOD_EINVAL;
+  if (!gemm_res_shape_ok(M, N, K, lda, ldw)) return LMOD_EUNSUPPORTED;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = C; p.bias = (const bf16_t*)bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc;
+  p.batch = 1; p.sA = 0; p.sB = 0; p.sC = 0; p.m_valid = nullptr; p.k_valid = nullptr;
+  p.act = 0; p.out_f32 = 0; p.accumulate = 0; p.vec_ok = 1;
+  p.C2 = const_cast<void*>(res); p.ldc2 = ldr; p.sC2 = 0; p.splitk = 1; p.kchunk = 0; p.ws = nullptr; p.counters = nullptr;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  launch_4<8>(p, (long long)p.tiles_m * p.tiles_n, stream);
   return lmod_launch_status();
 }
 

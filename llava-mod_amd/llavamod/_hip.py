@@ -15,6 +15,7 @@ _P, _I, _Q, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_floa
 # and takes the hipStream_t last ('p').  Kept in the same order as include/lmod_hip.h.
 SIGNATURES = {
     "lmod_gemm_bf16_nt": "pppp" + "iiiiii" + "iqqq" + "pp" + "iii" + "p",
+    "lmod_gemm_bf16_nt_res": "ppppp" + "iiiiiii" + "p",
     "lmod_gemm_qkv_rope_bf16": "pppp" + "iiiiii" + "ppp" + "i" + "p",
     "lmod_gemm_swiglu_bf16": "pppp" + "iiiiiii" + "iqqqq" + "p" + "p",
     "lmod_gemm_swiglu_bwd_bf16": "pppp" + "iiiiiii" + "iqqqq" + "p" + "p",

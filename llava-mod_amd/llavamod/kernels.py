@@ -3,6 +3,8 @@
 Every function here launches hand-written HIP kernels through `_hip.call`; there is no torch
 compute in this file (torch only allocates device memory).  Tensors are bf16 unless noted.
 """
+import os
+
 import torch
 
 from ._hip import call, ptr
@@ -39,6 +41,35 @@ def gemm_nt(a, b, bias=None, *, out=None, act=0, out_f32=False, accumulate=False
         sC = out.stride(0) if out.dim() == 3 else 0
     call("lmod_gemm_bf16_nt", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, lda, ldb, ldc, batch, sA, sB, sC,
          ptr(m_valid), ptr(k_valid), act, int(out_f32), int(accumulate))
+    return out
+
+
+def gemm_res_fusable(M, w, res):
+    """Can `gemm_nt_res` take the projection of a contiguous [M, K] operand through w [N, K] with residual res [M, N]?  Mirrors
+    lmod_gemm_bf16_nt's choice of the 4-wave 256-tile kernel (gemm.hip) — the only kernel with the residual epilogue;
+    LMOD_GEMM_RES=0 switches the fusion off (A/B runs)."""
+    if os.environ.get("LMOD_GEMM_RES", "1") == "0" or os.environ.get("LMOD_GEMM_WAVES", "0") not in ("", "0"):
+        return False
+    if res is None or res.dim() != 2 or res.stride(1) != 1 or w.dim() != 2 or w.stride(1) != 1:
+        return False
+    N, Kd = w.shape
+    if tuple(res.shape) != (M, N) or N % 8 or Kd % 8 or w.stride(0) % 8 or res.stride(0) % 8 or res.data_ptr() % 16:
+        return False
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    big = M >= 512 and N >= 256 and (t256 >= 160 or (t256 >= 96 and Kd >= 8192)) and \
+        ((M + 255) // 256 * 256) * ((N + 255) // 256 * 256) <= M * N * 115 // 100 + 65536
+    return big and 255 * Kd * 2 + Kd * 2 < 0x7fffffff and 255 * w.stride(0) * 2 + Kd * 2 < 0x7fffffff
+
+
+def gemm_nt_res(x, w, res, out=None):
+    """out[M, N] = bf16(res + bf16(x @ w^T)): a bias-free projection with the residual add in the GEMM epilogue (bit-identical to
+    gemm_nt followed by the residual path of rmsnorm_fwd)."""
+    M, Kd = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16)
+    call("lmod_gemm_bf16_nt_res", ptr(x), ptr(w), ptr(out), None, ptr(res), M, N, Kd, x.stride(0), w.stride(0), out.stride(0),
+         res.stride(0))
     return out
 
 

@@ -94,11 +94,19 @@ class Qwen2Attention(nn.Module):
     def trainable(self):
         return [p for p in self.parameters() if p.requires_grad]
 
-    def forward(self, x, rt, rows=None, inv_rows=None):
+    def res_fusable(self, x, res):
+        """Can forward() take the layer's residual stream into the o projection's epilogue?"""
+        return ops.res_fusable(x.shape[0], self._o.ensure(), res)
+
+    def forward(self, x, rt, rows=None, inv_rows=None, res=None):
+        """res: the residual stream [T, H]; the result is then res + attention(x) (callers check res_fusable first)."""
         spec = SimpleNamespace(qkv=self._qkv.ensure(), o=self._o.ensure(), B=rt.B, S=rt.S, nh=self.nh, nkv=self.nkv,
                                hd=self.hd, cos=rt.cos, sin=rt.sin, pos=rt.pos, scale=1.0 / math.sqrt(self.hd),
                                seqlens=rt.seqlens, rows=rows, inv_rows=inv_rows, cu=getattr(rt, "cu", None),
                                kv_out=(rt.cache.k[rt.layer], rt.cache.v[rt.layer]) if getattr(rt, "cache", None) is not None else None)
+        if res is not None:
+            assert rows is None
+            return ops.AttnBlockRes.apply(x, res, spec, *self.trainable())
         return ops.AttnBlock.apply(x, spec, *self.trainable())
 
     def forward_decode(self, x, rt):
@@ -130,8 +138,13 @@ class Qwen2MLP(nn.Module):
     def fused_weights(self):
         return [self._gu, self._down]
 
-    def forward(self, x, rt=None):
+    def res_fusable(self, x, res):
+        return ops.res_fusable(x.shape[0], self._down.ensure(), res)
+
+    def forward(self, x, rt=None, res=None):
         spec = SimpleNamespace(gu=self._gu.ensure(), down=self._down.ensure())
+        if res is not None:         # res + mlp(x), the add in the down projection's epilogue (callers check res_fusable first)
+            return ops.MLPBlockRes.apply(x, res, spec, *self.trainable())
         return ops.MLPBlock.apply(x, spec, *self.trainable())
 
 
@@ -146,9 +159,17 @@ class Qwen2DecoderLayer(nn.Module):
     def forward(self, delta, res, rt):
         """MoEQwen2DecoderLayer_forward (llava_qwen2_moe.py:143-179) on the (res, delta) stream."""
         n1, h = ops.AddRMSNorm.apply(delta, res, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
-        a = self.self_attn(n1, rt)
+        # the two residual adds of the layer (hidden = residual + attn / + mlp) run in the epilogues of the o and down projections
+        # where the 4-wave GEMM takes the shape (same roundings: bf16(res + bf16(acc))); the norm that follows then reads ONE tensor
+        # and writes one.  A sum that is already formed travels on as (delta = sum, res = None).
+        if self.self_attn.res_fusable(n1, h):
+            a, h = self.self_attn(n1, rt, res=h), None
+        else:
+            a = self.self_attn(n1, rt)
         n2, h2 = ops.AddRMSNorm.apply(a, h, self.post_attention_layernorm.weight,
                                       self.post_attention_layernorm.variance_epsilon)
+        if isinstance(self.mlp, Qwen2MLP) and self.mlp.res_fusable(n2, h2):
+            return self.mlp(n2, rt, res=h2), None, []
         m = self.mlp(n2, rt)
         moe_losses = []
         if isinstance(m, tuple) and len(m) == 3:      # MoE returns (out, l_aux, exp_counts)  (:161-164)

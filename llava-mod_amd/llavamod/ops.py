@@ -266,6 +266,11 @@ class AttnBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, spec, *params):
+        return AttnBlock._fwd(ctx, x, spec, None)
+
+    @staticmethod
+    def _fwd(ctx, x, spec, res):
+        """res (AttnBlockRes): the layer's residual stream, added in the o projection's epilogue."""
         B, S, nh, nkv, hd = spec.B, spec.S, spec.nh, spec.nkv, spec.hd
         if K.qkv_rope_fusable(x, spec.qkv.w, nh + nkv, hd):        # rotary embedding in the QKV GEMM's epilogue (one launch)
             qkv = K.gemm_qkv_rope(x, spec.qkv.w, spec.qkv.b, spec.cos, spec.sin, spec.pos, nh + nkv)
@@ -286,7 +291,7 @@ class AttnBlock(torch.autograd.Function):
         o, lse = K.attn_fwd(q, k, v, B, S, nh, nkv, hd, spec.scale, True, spec.seqlens, want_lse=need,
                             cu=getattr(spec, "cu", None))
         o_in = K.gather_rows(o, None, rows, o.shape[1]) if rows is not None else o    # o_proj on [R, nh*hd] only
-        out = linear_fwd(o_in, spec.o)
+        out = linear_fwd(o_in, spec.o) if res is None else K.gemm_nt_res(o_in, spec.o.w, res)
         ctx.spec = spec
         if need:
             ctx.save_for_backward(x if spec.qkv.requires_grad else None, qkv, o, lse, o_in if rows is not None else None)
@@ -317,6 +322,27 @@ class AttnBlock(torch.autograd.Function):
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class AttnBlockRes(torch.autograd.Function):
+    """(x, res) -> res + AttnBlock(x): hidden_states = residual + self_attn(...) (qwen2/modeling_qwen2.py:757-763) with the add
+    in the o projection's GEMM epilogue (bf16(res + bf16(o W^T)): the roundings of the two-step form).  The residual's gradient
+    is the output's."""
+
+    @staticmethod
+    def forward(ctx, x, res, spec, *params):
+        return AttnBlock._fwd(ctx, x, spec, res)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = AttnBlock.backward(ctx, dout)                 # (dx, None [spec], None per parameter ...) sized by needs_input_grad
+        return (g[0], dout) + tuple(g[2:])
+
+
+def res_fusable(rows, fw, res):
+    """Can the projection `fw` of a [rows, K] operand take the residual `res` in its epilogue?  (bias-free weight, a shape the
+    4-wave 256-tile kernel runs: kernels.gemm_res_fusable.)"""
+    return res is not None and fw.b is None and K.gemm_res_fusable(rows, fw.w, res)
+
+
 # ------------------------------------------------------------------------------------------ dense SwiGLU MLP
 class MLPBlock(torch.autograd.Function):
     """down(silu(gate(x)) * up(x)) (qwen2/modeling_qwen2.py:175-187): gate/up is ONE GEMM against the fused [2I, H]
@@ -324,6 +350,10 @@ class MLPBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, spec, *params):
+        return MLPBlock._fwd(ctx, x, spec, None)
+
+    @staticmethod
+    def _fwd(ctx, x, spec, res):
         need = _need(ctx)
         if spec.gu.b is None:
             act, gu = K.gemm_swiglu(x, spec.gu.w, want_gu=need)
@@ -331,7 +361,7 @@ class MLPBlock(torch.autograd.Function):
             gu = linear_fwd(x, spec.gu)
             I = spec.gu.w.shape[0] // 2
             act = K.swiglu_fwd(gu[:, :I], gu[:, I:])
-        out = linear_fwd(act, spec.down)
+        out = linear_fwd(act, spec.down) if res is None else K.gemm_nt_res(act, spec.down.w, res)
         ctx.spec = spec
         if need:
             ctx.save_for_backward(x, gu, act if spec.down.requires_grad else None)
@@ -358,6 +388,20 @@ class MLPBlock(torch.autograd.Function):
         if sp.gu.requires_grad:
             linear_wgrad(dgu, x, sp.gu)
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class MLPBlockRes(torch.autograd.Function):
+    """(x, res) -> res + MLPBlock(x): hidden_states = residual + mlp(...) (qwen2/modeling_qwen2.py:765-775) with the add in the down
+    projection's GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, res, spec, *params):
+        return MLPBlock._fwd(ctx, x, spec, res)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = MLPBlock.backward(ctx, dout)
+        return (g[0], dout) + tuple(g[2:])
 
 
 # ------------------------------------------------------------------------------------------ projector

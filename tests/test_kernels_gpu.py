@@ -144,6 +144,66 @@ def test_gemm_persistent_tile_walk(K_, persist_from_one_round):
     assert torch.equal(got, K_gemm(a, b)) and torch.equal(act, K.gemm_swiglu(a, wgu)[0]) and torch.equal(got3, K_gemm(a3, b3))
 
 
+@pytest.mark.parametrize("M,N,Kd", [(8192, 2048, 2048), (4096, 4096, 11008), (8232, 2176, 2048), (2048, 4096, 11008)])
+def test_gemm_residual_epilogue_is_the_two_step_form(M, N, Kd, monkeypatch):
+    """bf16(res + bf16(x W^T)) in the GEMM epilogue (gemm4_kernel<8>: the decoder layer's residual adds) = lmod_gemm_bf16_nt followed by
+    the residual path of lmod_rmsnorm_fwd, bit for bit — one tile per workgroup and persistent, ragged M / N edges included."""
+    x, w, res = rnd(M, Kd, seed=160), rnd(N, Kd, scale=0.03, seed=161), rnd(M, N, seed=162)
+    assert K.gemm_res_fusable(M, w, res)
+    delta = K_gemm(x, w)
+    _, _, h = K.rmsnorm_fwd(delta, torch.ones(N, device=DEV, dtype=BF), 1e-6, res=res)
+    assert torch.equal(h, (delta.float() + res.float()).to(BF))
+    monkeypatch.setenv("LMOD_GEMM_PERSIST", "0")
+    got = K.gemm_nt_res(x, w, res)
+    assert torch.equal(got, h), f"one tile per workgroup: {(got.float() - h.float()).abs().max().item()}"
+    monkeypatch.setenv("LMOD_GEMM_PERSIST", "1")
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_ROUNDS", "1")
+    got = K.gemm_nt_res(x, w, res)
+    assert torch.equal(got, h), f"persistent: {(got.float() - h.float()).abs().max().item()}"
+    # shapes the 256-tile kernel does not take are refused (the caller keeps the two-step form), and so is a bias
+    small = rnd(256, Kd, seed=163)
+    assert not K.gemm_res_fusable(256, w, rnd(256, N, seed=164))
+    with pytest.raises(RuntimeError):
+        K.gemm_nt_res(small, w, rnd(256, N, seed=164))
+
+
+def test_decoder_layer_with_fused_residual_adds_is_bit_identical(monkeypatch):
+    """A full-width dense decoder layer (H 2048, I 5504, 16 heads, T = 8192) forward + backward with the residual adds in the o / down
+    projections' epilogues (LMOD_GEMM_RES default) against the two-step form (LMOD_GEMM_RES=0): outputs and every gradient equal."""
+    from types import SimpleNamespace
+    from llavamod.engine import GradBuffer
+    from llavamod.model.language_model import qwen2_hip as Q
+    cfg = SimpleNamespace(hidden_size=2048, intermediate_size=5504, num_attention_heads=16, num_key_value_heads=16, head_dim=128,
+                          rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=2048)
+    torch.manual_seed(5)
+    layer = Q.Qwen2DecoderLayer(cfg, DEV)
+    for name, prm in layer.named_parameters():
+        if "layernorm" in name:
+            prm.data.fill_(1.0)
+        else:
+            prm.data.normal_(0, 0.02)
+    B, S = 4, 2048
+    cos, sin = Q.rope_tables(128, 2048, cfg.rope_theta, DEV)
+    pos = torch.arange(S, device=DEV, dtype=torch.int32).repeat(B)
+    rt = SimpleNamespace(B=B, S=S, cos=cos, sin=sin, pos=pos, seqlens=torch.full((B,), S, device=DEV, dtype=torch.int32))
+    gb = GradBuffer(layer)
+    delta0, res0 = rnd(B * S, 2048, seed=170), rnd(B * S, 2048, seed=171)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LMOD_GEMM_RES", flag)
+        gb.zero()
+        delta, res = delta0.clone().requires_grad_(True), res0.clone().requires_grad_(True)
+        m, h2, _ = layer(delta, res, rt)
+        assert (h2 is None) == (flag == "1")
+        total = m if h2 is None else (m.float() + h2.float()).to(BF)        # the next layer's add, done by hand for the two-step form
+        total.backward(rnd(B * S, 2048, seed=172))
+        torch.cuda.synchronize()
+        outs.append((total.detach().clone(), delta.grad.clone(), res.grad.clone(), gb.flat.clone()))
+    for a, b, name in zip(outs[0], outs[1], ("output", "d delta", "d res", "weight gradients")):
+        assert torch.isfinite(a.float()).all() and a.float().abs().max() > 0, name
+        assert torch.equal(a, b), f"{name}: fused != two-step ({(a.float() - b.float()).abs().max().item()})"
+
+
 def test_fused_qkv_rope_persistent_is_bit_identical(persist_from_one_round):
     # fused q/k/v projection + bias + RoPE on the persistent kernel (16 x 24 = 384 tiles) against the one-tile-per-workgroup launch
     # and against GEMM + the separate RoPE kernel
