@@ -645,7 +645,7 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128, K loop as one hand-placed asm statement, persistent workgroups from 10 rounds of the CUs up) @ teacher QKV [{gm}x{gn}x{gk}]",
+            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128, K loop as one hand-placed asm statement, persistent workgroups from 4 rounds of the CUs up) @ teacher QKV [{gm}x{gn}x{gk}]",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": round(gemm_ms, 4),
