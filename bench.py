@@ -135,12 +135,12 @@ def whole_step_object(units_per_s_per_gpu, stage):
 
 
 def in_step_gemm_aggregate(step_fn, step_index):
-    """The dominant kernel INSIDE the step: one extra, untimed optimizer step with every `lmod_gemm_bf16_nt` launch bracketed by
+    """The dominant kernel INSIDE the step: one extra, untimed optimizer step with every `lmod_gemm_bf16_nt` / `_nt_res` launch bracketed by
     events on its stream (`_hip.TRACE`); aggregate = sum of flops / sum of durations over the launches the library routes to
     the plain bf16 256-tile kernel (gemm4_kernel<7>: bf16 store, no accumulate, no row / reduction masks, >= 160 tiles).  The
     rocprofv3 figure of the same quantity is profiles/*_kernel_stats.md."""
     from llavamod import _hip
-    _hip.TRACE = {"names": {"lmod_gemm_bf16_nt"}, "rows": []}
+    _hip.TRACE = {"names": {"lmod_gemm_bf16_nt", "lmod_gemm_bf16_nt_res"}, "rows": []}
     try:
         torch.cuda.synchronize()
         step_fn(step_index, pipelined=False)       # the frozen model's pass inline: no second stream sharing the chip with the timed launches
@@ -151,9 +151,14 @@ def in_step_gemm_aggregate(step_fn, step_index):
     fl = ms = 0.0
     n = 0
     shapes = {}
-    for _, a, e0, e1 in rows:
-        M, N, Kd, batch, mv, kv, act, f32, accu = a[4], a[5], a[6], a[10], a[14], a[15], a[16], a[17], a[18]
-        if f32 or accu or mv or kv or act == 3 or M < 512 or N < 256:
+    for name, a, e0, e1 in rows:
+        if name == "lmod_gemm_bf16_nt_res":       # (A, W, C, bias, res, M, N, K, ...): the same loop, residual add in the epilogue (gemm4_kernel<8>)
+            M, N, Kd, batch = a[5], a[6], a[7], 1
+        else:
+            M, N, Kd, batch, mv, kv, act, f32, accu = a[4], a[5], a[6], a[10], a[14], a[15], a[16], a[17], a[18]
+            if f32 or accu or mv or kv or act == 3:
+                continue
+        if M < 512 or N < 256:
             continue
         if ((M + 255) // 256) * ((N + 255) // 256) * batch < 160:
             continue
@@ -165,7 +170,7 @@ def in_step_gemm_aggregate(step_fn, step_index):
     if not n:
         return None
     top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
-    return {"kernel": "gemm4_kernel<7> launches of ONE optimizer step (events around every launch; teacher pass inline for this step, so no second stream shares the chip)",
+    return {"kernel": "gemm4_kernel<7> / <8> (plain bf16 store / + residual add in the epilogue) launches of ONE optimizer step (events around every launch; teacher pass inline for this step, so no second stream shares the chip)",
             "launches": n, "ms": round(ms, 2), "achieved": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
             "by_shape": {k: {"launches": v[0], "ms": round(v[1], 2), "tflops": round(v[2] / v[1] / 1e9, 1)} for k, v in top}}
 
