@@ -113,20 +113,37 @@ def mimic_tflop(t_layers=32, s_dense=12, s_moe=12, vit_layers=23, S=2048, head_r
     return (teacher + s_fwd + s_dgrad + s_wgrad + 2 * vit) / 1e12
 
 
-def executed_tflop_per_sample(S=2048, rows=513):
+def executed_tflop_per_sample(S=2048, rows=513, E=4):
     """What this implementation issues: lm_head GEMMs (teacher fwd, student fwd + dgrad) and the o_proj + MLP of each
     model's LAST (dense) decoder layer on the 513 loss rows only."""
     skipped = S - rows
     t_last = skipped * (2 * 4096 * 4096 + 6 * 4096 * 11008)                       # teacher: forward only
     s_last = skipped * (2 * (2 * 2048 * 2048 + 6 * 2048 * 5504) + 6 * 2048 * 5504)  # student: fwd + dgrad (+ FFN wgrad)
-    return mimic_tflop(head_rows=rows) - (t_last + s_last) / 1e12
+    return mimic_tflop(head_rows=rows, E=E) - (t_last + s_last) / 1e12
 
 
-def whole_step_object(units_per_s_per_gpu, stage):
+def gemm_algorithmic_bytes(M, N, K, elem=2):
+    """Algorithmic HBM bytes of one C[M,N] = A[M,K] . B[N,K]^T launch: every operand and the result once."""
+    return (M * K + N * K + M * N) * elem
+
+
+def workload_name(stage, experts, world, ep):
+    """Exactly ONE BASELINE.json config per bench line."""
+    tail = f"CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({experts} experts, top-2, cf 1.5, 12 MoE layers, ep_size {ep}) student, Qwen1.5-7B teacher"
+    if stage == "dpo":
+        return "config 4: preference distillation (kto_pair), value = chosen/rejected PAIRS per second, " + tail
+    if experts == 8:
+        return "config 5: mimic distillation (kd_lm + moe aux), 8-expert top-2 student" + (" with expert-parallel all-to-all" if ep > 1 else " (ep_size 1: no exchange)") + ", " + tail
+    if world > 1:
+        return f"config 3: mimic distillation (kd_lm + moe aux), data parallel over {world} GPUs, " + tail
+    return "config 2: mimic distillation (kd_lm + moe aux), " + tail
+
+
+def whole_step_object(units_per_s_per_gpu, stage, E=4):
     """Whole-step MFMA utilisation.  PRIMARY: on the flops this implementation actually issues (lm_head and each model's last
     dense layer only on the loss rows); beside it the figure on BASELINE.md's algorithmic ledger (VERDICT r03 next #4)."""
     mult = 2.0 if stage == "dpo" else 1.0
-    ex, led = executed_tflop_per_sample() * mult, TFLOP_PER_SAMPLE_LEDGER * mult
+    ex, led = executed_tflop_per_sample(E=E) * mult, TFLOP_PER_SAMPLE_LEDGER * mult
     return {"frac_executed": round(ex * units_per_s_per_gpu / PEAK_BF16_TFLOPS, 4), "achieved_executed": round(ex * units_per_s_per_gpu, 1),
             "executed_tflop_per_unit": round(ex, 2),
             "frac_ledger": round(led * units_per_s_per_gpu / PEAK_BF16_TFLOPS, 4), "achieved_ledger": round(led * units_per_s_per_gpu, 1),
@@ -234,7 +251,7 @@ def _mem_total_gb():
     return 0.0
 
 
-def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None, stage="mimic"):
+def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None, stage="mimic", twin_device="cuda"):
     """The oracle (fp32 PyTorch restatement of the reference, oracle/) timed on this box's host cores on ONE sample of the
     same workload (config 2, B=1, S=2048): teacher forward + student forward/backward + losses (no optimizer step).
 
@@ -283,9 +300,12 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
         pair = dict(chosen_input_ids=b["input_ids"], chosen_labels=b["labels"], chosen_attention_mask=b["attention_mask"],
                     rejected_input_ids=rj["input_ids"], rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
                     images=b["images"])
+        hist, handles = _record_picks(o_student)
         t0 = time.time()
         _, logs = dpo_step(o_student, o_teacher, dict(pair, images=pair["images"].float()), beta=0.1, loss_type="kto_pair")
         t_cpu = time.time() - t0
+        for h in handles:
+            h.remove()
         tf = 2.0 * mimic_tflop(t_layers=t_l, s_dense=s_l // 2, s_moe=s_l // 2, vit_layers=vit_l)
         out = {"value": round(1.0 / t_cpu if full else (tf / t_cpu) / (2 * TFLOP_PER_SAMPLE_LEDGER), 5), "unit": "pairs/s", "cores": cores, "kind": "port",
                "sample": (f"oracle fp32 torch-CPU preference step (kto_pair) on ONE chosen/rejected pair, S=2048 each, "
@@ -300,17 +320,52 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                 _, outs = trainer.compute_loss(student, pair, return_outputs=True)
             for m, (d, n) in zip(moes, old):
                 m.deterministic, m.gate_noise = d, n
+            # FULL-DEPTH bf16 noise floor (VERDICT r04 next #1a): the oracle's bf16 twin on the same pair, once with the fp32
+            # run's expert picks forced (rounding only) and once routing on its own (rounding + its own near-tie flips)
+            tw_logs, twin_note = {}, None
+            if twin_device != "off":
+                try:
+                    from oracle import losses as olosses
+                    o_student.zero_grad(set_to_none=True)
+                    tdev = torch.device(twin_device if twin_device == "cpu" else next(student.parameters()).device)
+                    t0 = time.time()
+                    tw_s, tw_t = _oracle_twin(sc, vc, True, student, tdev), _oracle_twin(tc, vc, False, teacher, tdev)
+                    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(None)
+                    tp = _to_dev(pair, tdev)
+                    ch = dict(input_ids=tp["chosen_input_ids"], labels=tp["chosen_labels"], attention_mask=tp["chosen_attention_mask"], images=tp["images"])
+                    rj_ = dict(input_ids=tp["rejected_input_ids"], labels=tp["rejected_labels"], attention_mask=tp["rejected_attention_mask"], images=tp["images"])
+                    with torch.device(tdev), torch.no_grad():
+                        t_ch, t_rj = tw_t(**ch), tw_t(**rj_)
+                        for tag, forced in (("forced", True), ("free", False)):
+                            for m, h in zip(_oracle_moes(tw_s), hist):
+                                m.forced = [(a.to(tdev), b.to(tdev)) for a, b in h] if forced else None
+                            s_ch, s_rj = tw_s(**ch), tw_s(**rj_)
+                            _, tw_logs[tag] = olosses.preference_loss(s_ch, s_rj, t_ch, t_rj, 0.1, 0.0, "kto_pair", True)
+                            del s_ch, s_rj
+                    twin_note = (f"oracle bf16 twin (bf16 weights + activations, fp32 router) of both models at FULL depth on the same pair, "
+                                 f"eager torch on {tdev.type}, {time.time() - t0:.1f} s: floor_forced = |twin - fp32| / |fp32| with the fp32 run's expert picks "
+                                 "forced (rounding only), floor = the twin routing on its own (rounding + its own near-tie flips); the GPU product path routes on its own")
+                    del tw_s, tw_t, t_ch, t_rj
+                    if tdev.type == "cuda":
+                        torch.cuda.empty_cache()
+                except Exception as e:
+                    twin_note = "twin failed: " + repr(e)[:300]
             ld = {}
             for k in ("loss", "loss/reward", "loss/moe_balance", "rewards/chosen", "rewards/rejected", "rewards/margins",
                       "logps/chosen", "logps/rejected"):
                 g, c = float(outs[k].detach()), float(logs[k].detach())
-                ld[k] = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "abs": round(abs(g - c), 6),
-                         "rel": round(abs(g - c) / max(abs(c), 1e-30), 6)}
+                ld[k] = _floor_entry(g, c, float(tw_logs["forced"][k]) if "forced" in tw_logs else None,
+                                     float(tw_logs["free"][k]) if "free" in tw_logs else None)
             out["loss_delta"] = ld
+            if twin_note:
+                out["floor_note"] = twin_note
         return out
+    hist, handles = _record_picks(o_student) if full else ([], [])
     t0 = time.time()
     _, logs, _, _ = mimic_step(o_student, o_teacher, cb, loss_type="kd_lm")
     t_cpu = time.time() - t0
+    for h in handles:
+        h.remove()
     tf = mimic_tflop(t_layers=t_l, s_dense=s_l // 2, s_moe=s_l // 2, vit_layers=vit_l)
     rate = tf / t_cpu
     if full:
@@ -348,12 +403,48 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                 _, outs = trainer.compute_loss(student, b, return_outputs=True)
         for m, (d, n) in zip(moes, old):
             m.deterministic, m.gate_noise = d, n
+        # full-depth bf16 noise floor of the same quantities: the oracle's bf16 twin, forced picks and free-running
+        tw_logs, tw_grads, twin_note = {}, {}, None
+        if twin_device != "off":
+            try:
+                tdev = torch.device(twin_device if twin_device == "cpu" else next(student.parameters()).device)
+                t0 = time.time()
+                tw_s, tw_t = _oracle_twin(sc, vc, True, student, tdev), _oracle_twin(tc, vc, False, teacher, tdev)
+                freeze_like_d2s(tw_s)
+                tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(None)
+                tb = _to_dev(b, tdev)
+                for tag, forced in (("forced", True), ("free", False)):
+                    for m, h in zip(_oracle_moes(tw_s), hist):
+                        m.forced = (h[0][0].to(tdev), h[0][1].to(tdev)) if forced else None
+                    tw_s.zero_grad(set_to_none=True)
+                    with torch.device(tdev):
+                        _, tw_logs[tag], _, _ = mimic_step(tw_s, tw_t, tb, loss_type="kd_lm")
+                    if grad_cmp:
+                        tg = {n: p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
+                        tw_grads[tag] = {}
+                        for n in grad_cmp:
+                            og, g_ = ograd.get(hip_to_oracle_key(n)), tg.get(hip_to_oracle_key(n))
+                            if og is not None and g_ is not None:
+                                tw_grads[tag][n] = round(float((g_.detach().float().cpu() - og).norm() / og.norm().clamp_min(1e-30)), 5)
+                twin_note = (f"oracle bf16 twin (bf16 weights + activations, fp32 router) at FULL depth on the same sample, eager torch on {tdev.type}, "
+                             f"{time.time() - t0:.1f} s: floor_forced = |twin - fp32| / |fp32| with the fp32 run's expert picks forced, floor = the twin routing on its own")
+                del tw_s, tw_t
+                if tdev.type == "cuda":
+                    torch.cuda.empty_cache()
+            except Exception as e:
+                twin_note = "twin failed: " + repr(e)[:300]
         loss_delta = {}
         for k in ("loss", "loss/align", "loss/lm", "loss/moe_balance"):
             g, c = float(outs[k].detach()), float(logs[k].detach())
-            loss_delta[k] = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "rel": round(abs(g - c) / max(abs(c), 1e-30), 6)}
+            loss_delta[k] = _floor_entry(g, c, float(tw_logs["forced"][k]) if "forced" in tw_logs else None,
+                                         float(tw_logs["free"][k]) if "free" in tw_logs else None)
         if grad_cmp:
             loss_delta["grad_rel_frobenius_free_running"] = grad_cmp
+            if tw_grads:
+                loss_delta["grad_rel_frobenius_twin_forced"] = tw_grads.get("forced")
+                loss_delta["grad_rel_frobenius_twin_free_running"] = tw_grads.get("free")
+        if twin_note:
+            loss_delta["floor_note"] = twin_note
         sample = (f"oracle fp32 torch-CPU mimic step at FULL depth (32-layer teacher fwd + 24-layer MoE student fwd/bwd + "
                   f"23-layer ViT x2 + losses; no optimizer), B=1 S=2048, same weights and batch as the GPU models "
                   f"(host RAM {mem:.0f} GB): {tf:.2f} algorithmic TFLOP in {t_cpu:.1f} s = {rate:.2f} TFLOP/s")
@@ -371,6 +462,58 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
     except Exception as e:
         out["config1"] = {"error": repr(e)[:200]}
     return out
+
+
+def _oracle_twin(cfg, vcfg, moe, product_model, device):
+    """The oracle's bf16 twin of a product model (tests/test_step_parity_gpu.py::_bf16_twin at full depth): the SAME oracle
+    module with bf16 weights and activations (router `wg` kept fp32, as DeepSpeed keeps it), i.e. what the reference's own bf16
+    run computes through eager torch ops.  |twin - fp32 oracle| is the bf16 NOISE FLOOR of a logged quantity.  The twin is
+    test infrastructure like the oracle; by default it executes on the GPU (eager torch = the vendor BLAS the reference itself
+    would call there, seconds instead of ~10 minutes of host bf16 GEMMs); `--twin-device cpu` keeps it on the host cores."""
+    from oracle.llava import LlavaOracle, hip_to_oracle_key
+    with torch.device("meta"):
+        tw = LlavaOracle(cfg, vcfg, moe=moe)
+    sd = {}
+    for k, v in product_model.state_dict().items():
+        ok = hip_to_oracle_key(k)
+        sd[ok] = v.detach().to(device=device, dtype=torch.float32 if "gate.wg" in ok else torch.bfloat16, copy=True)
+    tw.load_state_dict(sd, strict=True, assign=True)
+    return tw
+
+
+def _oracle_moes(o):
+    return [l.mlp for l in o.lm.model.layers if hasattr(l.mlp, "deepspeed_moe")]
+
+
+def _record_picks(o_student):
+    """Forward hooks that keep every call's (idx1, idx2) of every MoE layer of an oracle student (the preference step calls
+    the student twice; `last_picks` alone would only hold the second call)."""
+    hist, handles = [], []
+    for m in _oracle_moes(o_student):
+        h = []
+        hist.append(h)
+        handles.append(m.register_forward_hook(lambda mod, inp, out, h=h: h.append((mod.last_picks[0].clone(), mod.last_picks[1].clone()))))
+    return hist, handles
+
+
+def _to_dev(batch, device):
+    return {k: (v.to(device=device, dtype=torch.bfloat16) if v.is_floating_point() else v.to(device)) if torch.is_tensor(v) else v
+            for k, v in batch.items()}
+
+
+def _floor_entry(g, c, tw_forced, tw_free):
+    """One logged scalar: GPU product path vs fp32 oracle, beside the twin's own distance from the fp32 oracle with the fp32
+    run's routing forced (pure rounding) and free-running (rounding + the twin's own near-tie flips)."""
+    den = max(abs(c), 1e-30)
+    e = {"gpu_bf16": round(g, 6), "cpu_fp32": round(c, 6), "abs": round(abs(g - c), 6), "rel": round(abs(g - c) / den, 6)}
+    if tw_forced is not None:
+        e["floor_forced"] = round(abs(tw_forced - c) / den, 6)
+    if tw_free is not None:
+        e["floor"] = round(abs(tw_free - c) / den, 6)
+        fl = max(e.get("floor_forced", 0.0), e["floor"])
+        e["within_1e-3"] = bool(e["rel"] <= 1e-3)
+        e["within_2x_floor"] = bool(e["rel"] <= max(2.0 * fl, 1e-3))
+    return e
 
 
 def _free_port():
@@ -474,8 +617,13 @@ def main():
                     help="with --ragged: unpadded (cu_seqlens) execution — no padding rows in any kernel (the MoE gate then does "
                          "not see padding rows either, unlike the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short config-4 (DPO) and config-5 (8-expert student) legs appended under `extra` at N=1")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
                     help="auto: full-depth oracle step (same weights, loss compared with the GPU) when host RAM >= 96 GB")
+    ap.add_argument("--twin-device", default="cuda", choices=["cuda", "cpu", "off"],
+                    help="where the oracle's full-depth bf16 twin (the noise floor printed beside every loss_delta) executes: eager "
+                         "torch on the GPU (seconds), the host cores (minutes), or not at all")
     ap.add_argument("--optimizer-overlap", action="store_true",
                     help="just-in-time AdamW on a second stream (bit-identical; measured 0.3 %% slower than serial, off by default)")
     ap.add_argument("--separate-towers", action="store_true", help="different random CLIP towers: both are run (no feature sharing)")
@@ -502,68 +650,100 @@ def main():
     dev = torch.device("cuda", local)
     B = args.micro_batch
 
-    student = LLaVAMoDQwen2ForCausalLM(student_cfg(args.experts), device=dev)
-    student.initialize_moe_modules(moe_model_args(args.experts, ep_size=args.ep))
-    for p in student.get_model().mm_projector.parameters():
-        p.requires_grad = True                                # initialize_vision_modules (llava_arch.py:115-120)
+    def build_student(experts):
+        st = LLaVAMoDQwen2ForCausalLM(student_cfg(experts), device=dev)
+        st.initialize_moe_modules(moe_model_args(experts, ep_size=args.ep))
+        for p in st.get_model().mm_projector.parameters():
+            p.requires_grad = True                            # initialize_vision_modules (llava_arch.py:115-120)
+        st.unpad = bool(args.unpad)
+        st.train()
+        gb_ = GradBuffer(st)
+        dp_ = DataParallel(zero2=not args.no_zero2, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
+                           ).attach(gb_, args.ep)
+        opt_ = HipAdamW(gb_, lr=2e-5, weight_decay=0.0, dp=dp_, max_grad_norm=args.max_grad_norm or None)
+        return st, gb_, dp_, opt_
+
+    student, gb, dp, opt = build_student(args.experts)
     teacher = LlavaQwen2ForCausalLM(teacher_cfg(), device=dev)
     if not args.separate_towers:
         # both models load the same frozen CLIP checkpoint in the reference's recipe (one --image_tower flag): give the
         # random-init teacher tower the student's weights, which lets the trainer compute the image features once per batch
         teacher.get_image_tower().load_state_dict(student.get_image_tower().state_dict())
-    student.unpad = teacher.unpad = bool(args.unpad)
-    student.train(); teacher.eval()
+    teacher.unpad = bool(args.unpad)
+    teacher.eval()
     n_train = sum(p.numel() for p in student.parameters() if p.requires_grad)
-    gb = GradBuffer(student)
-    dp = DataParallel(zero2=not args.no_zero2, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
-                      ).attach(gb, args.ep)
-    opt = HipAdamW(gb, lr=2e-5, weight_decay=0.0, dp=dp, max_grad_norm=args.max_grad_norm or None)
     A = args.grad_accum
-    if args.stage == "mimic":
-        trainer = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
-                                                                        loss_type="kd_lm", moe_loss_enable=True))())
-        batches = [synthetic_batch(B, 1000 * rank + i, ragged=args.ragged) for i in range(max(2, A))]
-    else:       # config 4: chosen / rejected pairs sharing the image; kto_pair is the shell default (preference_distillation.sh:29)
-        from llavamod.train.dpo_trainer import DPOTrainer
-        trainer = DPOTrainer(student, teacher, beta=0.1, loss_type="kto_pair")
-        batches = []
-        for i in range(max(2, A)):
-            ch, rj = synthetic_batch(B, 1000 * rank + i), synthetic_batch(B, 5000 + 1000 * rank + i)
-            batches.append(dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"],
-                                chosen_attention_mask=ch["attention_mask"], rejected_input_ids=rj["input_ids"],
-                                rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
-                                images=ch["images"]))
     total = args.steps + args.warmup
-
-    # Teacher pipelining (mimic stage): the frozen teacher's forward for batch i+1 is issued on a side stream before the
-    # student's step i, so the two streams' MFMA-bound and HBM-bound kernels overlap.  Every step still runs exactly one
-    # teacher forward and one student forward/backward/optimizer update; the device-wide synchronize() that closes the
-    # timed region also waits for the last teacher pass.
     pipelined = not args.no_teacher_prefetch
-    prefetch = trainer.prefetch_teacher if args.stage == "mimic" else trainer.prefetch_reference
-    state = {"teacher": prefetch(batches[0]) if pipelined else None}
 
-    nb = len(batches)
+    def make_workload(stage, st, gb_, dp_, opt_, mb, seed0=0):
+        """(trainer, step function) of one workload: stage "mimic" (configs 2 / 3 / 5) or "dpo" (config 4) on student `st`.
 
-    def step(i, pipelined=pipelined):
-        """One optimizer step = A micro-batches (gradients accumulate in the fp32 buffer; the exchange is armed on the
-        last one only) + gradient exchange + clipping + AdamW."""
-        gb.zero()
-        for a in range(A):
-            k = i * A + a
-            dp.armed = (a == A - 1)
-            if pipelined:
-                nxt = prefetch(batches[(k + 1) % nb])
-                kw = {"teacher" if args.stage == "mimic" else "reference": state["teacher"]}
-                loss = trainer.training_step(student, batches[k % nb], **kw)
-                state["teacher"] = nxt
-            else:
-                loss = trainer.training_step(student, batches[k % nb])
-        dp.finish()                      # spans were exchanged asynchronously as the last backward produced them
-        # the reference averages the loss over the accumulation window and the ranks: fold both means into the scale
-        opt.step(grad_scale=1.0 / (world * A), lr=warmup_cosine(i, max(total, 100), 2e-5), overlap=args.optimizer_overlap,
-                 clear_grads=True)          # gradients are cleared inside the AdamW pass: no separate 8 GB memset
-        return loss
+        Teacher pipelining: the frozen model's forward for batch i+1 is issued on a side stream before the student's step i, so the
+        two streams' MFMA-bound and HBM-bound kernels overlap.  Every step still runs exactly one frozen-model pass per micro-batch
+        and one student forward/backward/optimizer update; the device-wide synchronize() that closes a timed region also waits for
+        the last frozen-model pass."""
+        if stage == "mimic":
+            tr = AlignTrainer(st, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+                                                                   loss_type="kd_lm", moe_loss_enable=True))())
+            bs = [synthetic_batch(mb, seed0 + 1000 * rank + i, ragged=args.ragged) for i in range(max(2, A))]
+            pf, key = tr.prefetch_teacher, "teacher"
+        else:   # config 4: chosen / rejected pairs sharing the image; kto_pair is the shell default (preference_distillation.sh:29)
+            from llavamod.train.dpo_trainer import DPOTrainer
+            tr = DPOTrainer(st, teacher, beta=0.1, loss_type="kto_pair")
+            bs = []
+            for i in range(max(2, A)):
+                ch, rj = synthetic_batch(mb, seed0 + 1000 * rank + i), synthetic_batch(mb, seed0 + 5000 + 1000 * rank + i)
+                bs.append(dict(chosen_input_ids=ch["input_ids"], chosen_labels=ch["labels"],
+                               chosen_attention_mask=ch["attention_mask"], rejected_input_ids=rj["input_ids"],
+                               rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
+                               images=ch["images"]))
+            pf, key = tr.prefetch_reference, "reference"
+        state = {"h": pf(bs[0]) if pipelined else None}
+        nb_ = len(bs)
+
+        def step_fn(i, pipelined=pipelined):
+            """One optimizer step = A micro-batches (gradients accumulate in the fp32 buffer; the exchange is armed on the
+            last one only) + gradient exchange + clipping + AdamW."""
+            gb_.zero()
+            for a in range(A):
+                k = i * A + a
+                dp_.armed = (a == A - 1)
+                if pipelined:
+                    nxt = pf(bs[(k + 1) % nb_])
+                    loss = tr.training_step(st, bs[k % nb_], **{key: state["h"]})
+                    state["h"] = nxt
+                else:
+                    loss = tr.training_step(st, bs[k % nb_])
+            dp_.finish()                     # spans were exchanged asynchronously as the last backward produced them
+            # the reference averages the loss over the accumulation window and the ranks: fold both means into the scale
+            opt_.step(grad_scale=1.0 / (world * A), lr=warmup_cosine(i, max(total, 100), 2e-5), overlap=args.optimizer_overlap,
+                      clear_grads=True)      # gradients are cleared inside the AdamW pass: no separate 8 GB memset
+            return loss
+        return tr, step_fn
+
+    def timed(step_fn, warm, steps, first=0):
+        """`warm` untimed + `steps` timed optimizer steps, barrier + synchronize on both sides, MAX over ranks: seconds."""
+        for i in range(warm):
+            step_fn(first + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = step_fn(first + warm + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, last
+
+    trainer, step = make_workload(args.stage, student, gb, dp, opt, B)
 
     if pipelined:
         # the student step is the critical path: it runs on a HIGH-priority stream, so the dispatcher serves its kernels
@@ -573,22 +753,8 @@ def main():
         torch.cuda.set_stream(hp)
     for i in range(args.warmup):
         step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     comm0 = {k: list(v) for k, v in engine.COMM.items()}
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, last = timed(step, 0, args.steps, first=args.warmup)
     loss_val = float(last)
 
     if rank == 0:
@@ -614,25 +780,24 @@ def main():
         del a, w, o
         in_step = in_step_gemm_aggregate(step, args.warmup + args.steps)
         optimizer_ms = time_optimizer(gb, opt, world * A)
-        # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live)
-        traffic, traffic_note = None, "no committed PMC pass for this shape"
-        tp = next((t for t in (os.path.join(ROOT, "profiles", f) for f in ("r04_final_gemm_traffic.json", "r03_final_gemm_traffic.json", "r02_final_gemm_traffic.json", "r01_final_gemm_traffic.json"))
-                   if os.path.exists(t)), "")
+        # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live); the
+        # ALGORITHMIC bytes are computed here from the shape this function launches: A + B + C once, bf16
+        algo_bytes = gemm_algorithmic_bytes(gm, gn, gk)
+        traffic, traffic_note = None, f"no committed PMC pass for this shape; algorithmic {algo_bytes / 1e9:.2f} GB"
+        tp = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_final_gemm_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(t)), "")
         if tp:
             tj = json.load(open(tp))
             if tj["shape"] == [gm, gn, gk]:
                 traffic = round((tj["fetch_bytes_corrected"] + tj["write_bytes"]) / 1e9, 2)
                 traffic_note = (f"GB per launch at the L2/fabric boundary (Infinity-Cache hits included), {tj['source']}; "
-                                f"algorithmic {tj['algorithmic_bytes'] / 1e9:.2f} GB — see profiles/{os.path.basename(tp).replace('gemm_traffic.json', 'pmc.md')}")
+                                f"algorithmic (A + B + C once, bf16) {algo_bytes / 1e9:.2f} GB => {traffic * 1e9 / algo_bytes:.2f}x — see "
+                                f"profiles/{os.path.basename(tp).replace('gemm_traffic.json', 'pmc.md')}")
         out = {
             "metric": "distillation samples/sec (336px img + 2k ctx), 2B-MoE student / 7B teacher",
             "value": round(sps, 4), "unit": "samples/s" if args.stage == "mimic" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, seeded image/token batches)",
-            "config": {"workload": ("config 2/3/5: mimic distillation (kd_lm + moe aux)" if args.stage == "mimic" else
-                                    "config 4: preference distillation (kto_pair), value = chosen/rejected PAIRS per second") +
-                                   f", CLIP-ViT-L/14-336 + Qwen1.5-1.8B-MoE ({args.experts} experts, top-2, cf 1.5, 12 MoE layers, "
-                                   f"ep_size {args.ep}) student, Qwen1.5-7B teacher",
+            "config": {"workload": workload_name(args.stage, args.experts, world, args.ep),
                        "batch_shape": ("dense: every sample 2048 tokens" if not args.ragged else
                                        "ragged: text lengths U[600,1473] right-padded (SURVEY 8d variant), " +
                                        ("unpadded cu_seqlens execution" if args.unpad else "padded execution with key masks")),
@@ -656,15 +821,53 @@ def main():
                          "launch_ms": round(gemm_ms, 4),
                          "achieved_note": "live micro-launch: 10 launches at the teacher-QKV shape, HIP events on the launch stream",
                          "in_step": in_step,
-                         "whole_step": whole_step_object(sps / world, args.stage)},
+                         "whole_step": whole_step_object(sps / world, args.stage, args.experts)},
             "optimizer_ms": optimizer_ms,
             "exchange": exchange_object(dp, opt, args.steps, comm0),
         }
+        want_extras = (world == 1 and not args.no_extras and args.stage == "mimic" and args.experts == 4 and not args.ragged
+                       and B == 16 and args.ep == 1)
+        if want_extras:
+            # config 4 on the SAME models (VERDICT r04 next #1b): the preference stage's own step — 8 pairs x accum (two student
+            # forward/backward passes + two frozen-model passes per pair), kto_pair, optimizer inside — 1 warm-up + 3 timed steps
+            try:
+                _, step4 = make_workload("dpo", student, gb, dp, opt, 8, seed0=70000)
+                dt4, l4 = timed(step4, 1, 3, first=total + 2)
+                pps = 3 * 8 * A / dt4
+                out["extra"] = {"config4_pairs_per_s": {
+                    "value": round(pps, 4), "unit": "pairs/s", "ms_per_step": round(dt4 / 3 * 1e3, 2), "steps": 3, "warmup": 1,
+                    "workload": workload_name("dpo", 4, 1, 1), "micro_batch_pairs": 8, "grad_accum": A,
+                    "frac_executed": whole_step_object(pps, "dpo")["frac_executed"], "frac_ledger": whole_step_object(pps, "dpo")["frac_ledger"],
+                    "final_loss": round(float(l4), 4)}}
+                del step4
+            except Exception as e:
+                out["extra"] = {"config4_pairs_per_s": {"error": repr(e)[:300]}}
         if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:
-                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer, args.cpu_baseline, gb=gb, stage=args.stage)
+                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer, args.cpu_baseline, gb=gb, stage=args.stage, twin_device=args.twin_device)
             except Exception as e:                              # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+        if want_extras:
+            # config 5's student (8 experts, top-2; ep_size 1 on one GPU) through the headline's own step: the 4-expert student
+            # and its optimizer state are released first, 1 warm-up + 3 timed steps
+            try:
+                import gc
+                trainer = step = student = gb = dp = opt = None
+                gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+                st8, gb8, dp8, opt8 = build_student(8)
+                if not args.separate_towers:
+                    st8.get_image_tower().load_state_dict(teacher.get_image_tower().state_dict())
+                _, step8 = make_workload("mimic", st8, gb8, dp8, opt8, B, seed0=90000)
+                dt8, l8 = timed(step8, 1, 3, first=total + 8)
+                sps8 = 3 * B * A / dt8
+                out.setdefault("extra", {})["config5_samples_per_s"] = {
+                    "value": round(sps8, 4), "unit": "samples/s", "ms_per_step": round(dt8 / 3 * 1e3, 2), "steps": 3, "warmup": 1,
+                    "workload": workload_name("mimic", 8, 1, 1), "micro_batch_per_gpu": B, "grad_accum": A,
+                    "frac_executed": whole_step_object(sps8, "mimic", 8)["frac_executed"], "frac_ledger": whole_step_object(sps8, "mimic", 8)["frac_ledger"],
+                    "trainable_params": sum(p.numel() for p in st8.parameters() if p.requires_grad), "final_loss": round(float(l8), 4),
+                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+            except Exception as e:
+                out.setdefault("extra", {})["config5_samples_per_s"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
