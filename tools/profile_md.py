@@ -2,21 +2,41 @@
 usage: python tools/profile_md.py gpurun_out/final profiles/r01_final"""
 import collections, csv, glob, json, os, sys
 
-src, dst = sys.argv[1], sys.argv[2]
+src, dst = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("", "")
 TAG = os.path.basename(dst).replace("_", " ")
+
+
+LAYERS_QKV = 24 + 32          # decoder layers of the config-2 student + teacher: one fused QKV + RoPE launch each per micro-batch
+
+
+def steps_in_trace(qkv_rope_launches, grad_accum, layers=LAYERS_QKV):
+    """Optimizer steps a kernel trace holds, from its own `gemm4_kernel<5>` (fused QKV + RoPE) launch count."""
+    per_step = layers * grad_accum
+    return qkv_rope_launches / per_step if per_step and qkv_rope_launches else 0
+
+
+def gemm_algorithmic_bytes(M, N, K, elem=2):
+    """A + B + C once (the same formula bench.py prints)."""
+    return (M * K + N * K + M * N) * elem
 
 
 def stats_md():
     rows = list(csv.DictReader(open(f"{src}/bench/a_kernel_stats.csv")))
     trace = list(csv.DictReader(open(f"{src}/bench/a_kernel_trace.csv")))
     line = json.loads(open(f"{src}/bench_line.json").read())
-    n_steps = line["steps"] + line["warmup"]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    # optimizer steps actually inside the trace: timed + warm-up + bench.py's extra in-step-aggregate step (+ anything else that
+    # ran the models) — counted from the trace itself instead of trusted from argv: every student layer launches the fused
+    # QKV + RoPE GEMM (`gemm4_kernel<5`) once per micro-batch, and so does every teacher layer
+    A = line["config"].get("grad_accum", 1)
+    qkv_calls = sum(1 for r in trace if "gemm4_kernel<5" in r["Kernel_Name"])
+    n_steps = steps_in_trace(qkv_calls, A) or (line["steps"] + line["warmup"])
     out = [f"# rocprofv3 --kernel-trace --stats of the default bench workload ({TAG})", "",
            "Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
            "--no-cpu-baseline --no-teacher-prefetch` (teacher pipelining off so that kernel durations do not overlap; the "
            "default bench line with pipelining on is in `*_bench_n1.json`).", "",
-           f"{n_steps} optimizer steps (1 warm-up + 3 timed) of {line['config'].get('grad_accum', 1)} micro-batches x "
+           f"{n_steps:g} optimizer steps in the trace ({line['warmup']} warm-up + {line['steps']} timed + the in-step-aggregate step; counted from the "
+           f"{qkv_calls} fused QKV + RoPE launches = {LAYERS_QKV} layers x {A} micro-batches per step) of {A} micro-batches x "
            f"{line['config']['micro_batch_per_gpu']} samples, config 2.  Sum of kernel "
            f"time {tot / 1e6:.1f} ms = {tot / 1e6 / n_steps:.1f} ms/step; bench wall clock under the profiler "
            f"{line['ms_per_step']} ms/step ({line['value']} samples/s).  Model construction is inside the trace (torch "
@@ -108,7 +128,7 @@ def pmc_md():
     c, us = g[k]
     fetch_kb, write_kb = f[k][0]["FETCH_SIZE"], w[k][0]["WRITE_SIZE"]
     M, N, Kd = 32768, 12288, 4096
-    algo = (M * Kd + N * Kd + M * N) * 2
+    algo_nt = gemm_algorithmic_bytes(M, N, Kd)
     clk = c["GRBM_GUI_ACTIVE"] / 8 / us / 1e3
     out += [f"## `{kname}` at the teacher QKV shape [{M} x {N} x {Kd}] (`python tools/gemm_one.py`)", "",
             f"* duration under the counter passes: {us:.0f} us ({2.0 * M * N * Kd / us / 1e6:.0f} TFLOP/s; counter collection and its lower "
@@ -119,7 +139,7 @@ def pmc_md():
             f"{c['SQ_LDS_IDX_ACTIVE'] / 256 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.0f} % of cycles",
             f"* memory side: FETCH_SIZE {fetch_kb / 1e6:.3f} GB x 2 (gfx950 16-byte-lane correction, MI355X_MICROARCH.md §HBM) = "
             f"**{2 * fetch_kb / 1e6:.2f} GB**, WRITE_SIZE **{write_kb / 1e6:.2f} GB** per launch; algorithmic bytes (A + B + C once) "
-            f"{algo / 1e9:.2f} GB.  The fetch figure counts every L2 miss at the fabric, Infinity-Cache hits included: an XCD's 32 "
+            f"{algo_nt / 1e9:.2f} GB => {(2 * fetch_kb * 1e3 + write_kb * 1e3) / algo_nt:.2f}x.  The fetch figure counts every L2 miss at the fabric, Infinity-Cache hits included: an XCD's 32 "
             "concurrent 256x256 tiles form a 4 x 8 rectangle that needs 12 operand panels per K sweep, 24 sweeps per XCD "
             "=> ~4.8 GB by construction; the 256 MB Infinity Cache absorbs the re-reads (B = 0.10 GB stays resident), so this is "
             "~2 TB/s of fabric traffic under an MFMA-bound kernel, not HBM over-fetch.",
@@ -131,7 +151,7 @@ def pmc_md():
         c, us = t[tk]
         live = 9000 + 12500 + 20036 + 24000
         flop = 2.0 * live * 11008 * 2048
-        algo = (live * (11008 + 2048) * 2 + 4 * 11008 * 2048 * 8)
+        algo_tn = (live * (11008 + 2048) * 2 + 4 * 11008 * 2048 * 8)
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         out += ["", "## `gemm4t_kernel<false>` (weight gradients on reduction-major operands) at the MoE gate+up shape: 4 experts x [11008 x 2048], "
                 f"{live} live rows (`python tools/wgrad_one.py`)", "",
@@ -141,7 +161,7 @@ def pmc_md():
                 f"(the padded, XOR-free image; `tools/probe/gemm4t_layout.py` predicts zero), LDS active {c['SQ_LDS_IDX_ACTIVE'] / 256 / cyc * 100:.0f} % of CU cycles "
                 "(twice the instructions of the NT kernel's `ds_read_b128` for the same bytes)",
                 f"* memory side: FETCH_SIZE x 2 = **{2 * tf[tk][0]['FETCH_SIZE'] / 1e6:.2f} GB**, WRITE_SIZE **{tw[tk][0]['WRITE_SIZE'] / 1e6:.2f} GB** per launch; "
-                f"algorithmic bytes (live rows of dY and X once, fp32 C read + written) {algo / 1e9:.2f} GB",
+                f"algorithmic bytes (live rows of dY and X once, fp32 C read + written) {algo_tn / 1e9:.2f} GB",
                 "", "| counter | per dispatch |", "|---|---|"]
         out += [f"| {a_} | {b_:.4g} |" for a_, b_ in sorted(c.items())]
     a = pmc("attn_sq")
@@ -167,14 +187,15 @@ def pmc_md():
                        f"{c['SQ_ACTIVE_INST_VALU'] / 1e6:.1f} | {c['SQ_ACTIVE_INST_LDS'] / 1e6:.1f} | {c['SQ_WAIT_INST_LDS'] / 1e6:.1f} |")
     open(dst + "_pmc.md", "w").write("\n".join(out) + "\n")
     json.dump({"kernel": kname, "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
-               "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo,
+               "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo_nt,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md §HBM"},
               open(dst + "_gemm_traffic.json", "w"), indent=1)
 
 
-stats_md()
-pmc_md()
-os.system(f"cp {src}/kernel_microbench.jsonl {dst}_kernel_microbench.jsonl; grep -h weighted8 {src}/gemm_shapes.json > {dst}_gemm_shapes.json")
-os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
-if os.path.exists(f"{src}/attn_bench.jsonl"):
-    os.system(f"cp {src}/attn_bench.jsonl {dst}_attn_bench.jsonl")
+if __name__ == "__main__":
+    stats_md()
+    pmc_md()
+    os.system(f"cp {src}/kernel_microbench.jsonl {dst}_kernel_microbench.jsonl; grep -h weighted8 {src}/gemm_shapes.json > {dst}_gemm_shapes.json")
+    os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
+    if os.path.exists(f"{src}/attn_bench.jsonl"):
+        os.system(f"cp {src}/attn_bench.jsonl {dst}_attn_bench.jsonl")
