@@ -329,7 +329,7 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                     o_student.zero_grad(set_to_none=True)
                     tdev = torch.device(twin_device if twin_device == "cpu" else next(student.parameters()).device)
                     t0 = time.time()
-                    tw_s, tw_t = _oracle_twin(sc, vc, True, student, tdev), _oracle_twin(tc, vc, False, teacher, tdev)
+                    tw_s, tw_t = cpu_baseline_twin(sc, vc, True, student, tdev), cpu_baseline_twin(tc, vc, False, teacher, tdev)
                     tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(None)
                     tp = _to_dev(pair, tdev)
                     ch = dict(input_ids=tp["chosen_input_ids"], labels=tp["chosen_labels"], attention_mask=tp["chosen_attention_mask"], images=tp["images"])
@@ -409,7 +409,7 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
             try:
                 tdev = torch.device(twin_device if twin_device == "cpu" else next(student.parameters()).device)
                 t0 = time.time()
-                tw_s, tw_t = _oracle_twin(sc, vc, True, student, tdev), _oracle_twin(tc, vc, False, teacher, tdev)
+                tw_s, tw_t = cpu_baseline_twin(sc, vc, True, student, tdev), cpu_baseline_twin(tc, vc, False, teacher, tdev)
                 freeze_like_d2s(tw_s)
                 tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(None)
                 tb = _to_dev(b, tdev)
@@ -464,7 +464,7 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
     return out
 
 
-def _oracle_twin(cfg, vcfg, moe, product_model, device):
+def cpu_baseline_twin(cfg, vcfg, moe, product_model, device):
     """The oracle's bf16 twin of a product model (tests/test_step_parity_gpu.py::_bf16_twin at full depth): the SAME oracle
     module with bf16 weights and activations (router `wg` kept fp32, as DeepSpeed keeps it), i.e. what the reference's own bf16
     run computes through eager torch ops.  |twin - fp32 oracle| is the bf16 NOISE FLOOR of a logged quantity.  The twin is

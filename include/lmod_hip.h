@@ -217,7 +217,9 @@ int lmod_lossplan_fill(const long long* labels, int B, int S, int kd_rows, int c
 int lmod_row_argmax_bf16(const void* logits, long long ld, int V, int* out, int R, hipStream_t stream);
 
 /* ---- sparse MoE (DeepSpeed 0.9.5 TopKGate/top1gating/top2gating/MOELayer semantics) ------------
- * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32). */
+ * logits[T,E] = x.float() @ wg^T  (TopKGate.forward; wg kept fp32).
+ * Experts per layer: 1 <= E <= 32 (`--num_experts`, config/args.py:46); the per-token kernels are instantiated for
+ * ME = 8 / 16 / 32 expert slots and picked by E. */
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream);
 /* top-k (k in {1,2}) gating with capacity C: token-order slot assignment, drops, renormalised
  * combine weights, l_aux, exp_counts, slots_used[E] (live rows per capacity slab).
@@ -226,7 +228,8 @@ int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, in
  * k = 1 (top1gating): `noise` [T,E] holds the random-token-selection priorities (use_rts=True: per expert the C tokens
  *   with the largest priority keep their slot, survivors numbered in token order; NULL: token order, use_rts=False);
  *   noise_mode 2 draws U(0,1) priorities in the kernel.
- * noise_out (nullable, [T,E]) receives the drawn noise.  scratch: 4*T + 24*ceil(T/512) int32. */
+ * noise_out (nullable, [T,E]) receives the drawn noise.  scratch: 4*T + 3*ME*ceil(T/512) int32, ME = 8 / 16 / 32 for
+ *   E <= 8 / 16 / 32. */
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
                   int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, int noise_mode,
@@ -251,7 +254,7 @@ int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float
  * 2-way `coefficient` Linear(hidden, 2); roundings follow the bf16 module.  p[T,2] (fp32) is saved for the backward,
  * which returns d_moe, d_mlp (bf16) and d_coef_logits[T,2] (fp32).  coef_logits come from lmod_moe_router_fwd (E = 2),
  * the coefficient weight gradient from lmod_moe_router_wgrad, its input gradient from lmod_small_linear_dgrad:
- * dx[T,H] (bf16) = dlogits[T,E] @ w[E,H] (fp32, E <= 8, H % 8 == 0). */
+ * dx[T,H] (bf16) = dlogits[T,E] @ w[E,H] (fp32, E <= 32, H % 8 == 0). */
 int lmod_moe_residual_mix_fwd(const void* moe_out, const void* mlp_out, const float* coef_logits, const float* coef_bias,
                               void* out, float* p, int T, int H, hipStream_t stream);
 int lmod_moe_residual_mix_bwd(const void* dout, const void* moe_out, const void* mlp_out, const float* p, void* d_moe,

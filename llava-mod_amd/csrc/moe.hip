@@ -11,7 +11,16 @@
 // Dispatch itself is lmod_gather_rows with slot_token as the index (empty slots -> zero rows).
 #include "common.h"
 
-#define MAXE 8
+// Experts per layer: the per-token kernels keep one value per expert in registers, so they are compiled for ME = 8 / 16 / 32
+// slots and dispatched on E (`ME_DISPATCH`): E <= 8 — the reference shells' 4 and config 5's 8 — runs exactly the code it
+// always ran; `--num_experts` up to LMOD_MAX_EXPERTS = 32 takes the wider instantiations.  The two kernels whose per-expert
+// state is a register TILE (router logits: 4 tokens x E; router wgrad: E x 8 columns) walk the experts in groups of 8
+// (grid.y / grid.z), so their register footprint does not grow with E.
+#define MAXE 32
+#define EG 8
+#define ME_DISPATCH(E, CALL) do { if ((E) <= 8) { constexpr int ME = 8; CALL; } else if ((E) <= 16) { constexpr int ME = 16; CALL; } \
+                                 else { constexpr int ME = 32; CALL; } } while (0)
+static inline int me_of(int E) { return E <= 8 ? 8 : (E <= 16 ? 16 : 32); }
 
 // ---------------------------------------------------------------- router logits (fp32)
 __global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wg,
@@ -19,11 +28,14 @@ __global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restric
   const int lane = threadIdx.x & 63;
   const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;     // 4 tokens per wave
   if (t0 >= T) return;
-  float acc[4][MAXE];
+  const int eb = blockIdx.y * EG;                               // this block's group of 8 experts
+  wg += (long long)eb * H;
+  const int En = min(E - eb, EG);
+  float acc[4][EG];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) acc[a][e] = 0.f;
+    for (int e = 0; e < EG; ++e) acc[a][e] = 0.f;
   const int nch = H >> 3;
   for (int c = lane; c < nch; c += 64) {
     float xv[4][8];
@@ -39,8 +51,8 @@ __global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restric
       }
     }
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      if (e < E) {
+    for (int e = 0; e < EG; ++e) {
+      if (e < En) {
         const f32x4 w0 = *(const f32x4*)(wg + (long long)e * H + c * 8);
         const f32x4 w1 = *(const f32x4*)(wg + (long long)e * H + c * 8 + 4);
 #pragma unroll
@@ -53,10 +65,10 @@ __global__ __launch_bounds__(256) void router_fwd_kernel(const bf16_t* __restric
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      if (e < E) {
+    for (int e = 0; e < EG; ++e) {
+      if (e < En) {
         const float s = wave_sum(acc[a][e]);
-        if (lane == 0 && t0 + a < T) logits[(long long)(t0 + a) * E + e] = s;
+        if (lane == 0 && t0 + a < T) logits[(long long)(t0 + a) * E + eb + e] = s;
       }
     }
 }
@@ -75,11 +87,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
   }
 }
 // u in (0, 1): 24 random bits + half a step.  mode 1: Gumbel(0,1) = -log(-log(u)); mode 2: the uniform itself.
-__device__ __forceinline__ void draw_noise(float (&nz)[MAXE], long long t, int E, unsigned long long seed,
+template <int ME>
+__device__ __forceinline__ void draw_noise(float (&nz)[ME], long long t, int E, unsigned long long seed,
                                            unsigned long long offset, int mode) {
   const unsigned long long ctr = offset + (unsigned long long)t;
 #pragma unroll
-  for (int grp = 0; grp < MAXE / 4; ++grp) {
+  for (int grp = 0; grp < ME / 4; ++grp) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)grp, 0u};
     if (grp * 4 < E) philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
@@ -94,6 +107,7 @@ __device__ __forceinline__ void draw_noise(float (&nz)[MAXE], long long t, int E
 // noise_mode 0: `noise` ([T,E], may be NULL) is what the caller supplies; 1 / 2: Gumbel / uniform noise is drawn here
 // (and written to noise_out if the caller wants to see it).  k == 2: the noise is added to the logits for the SECOND
 // pick (top2gating).  k == 1: the noise is the random-token-selection priority (top1gating, use_rts), consumed later.
+template <int ME>
 __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
                                                        float* __restrict__ gates, int* __restrict__ idx1,
                                                        int* __restrict__ idx2, int T, int E, int k, int noise_mode,
@@ -101,31 +115,31 @@ __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict_
                                                        float* __restrict__ noise_out, float* __restrict__ prio) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
-  float nz[MAXE];
+  float nz[ME];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) nz[e] = 0.f;
+  for (int e = 0; e < ME; ++e) nz[e] = 0.f;
   bool have_noise = (noise != nullptr);
   if (noise_mode) {
     draw_noise(nz, t, E, seed, offset, noise_mode);
     have_noise = true;
     if (noise_out) {
 #pragma unroll
-      for (int e = 0; e < MAXE; ++e) if (e < E) noise_out[(long long)t * E + e] = nz[e];
+      for (int e = 0; e < ME; ++e) if (e < E) noise_out[(long long)t * E + e] = nz[e];
     }
   } else if (noise) {
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) if (e < E) nz[e] = noise[(long long)t * E + e];
+    for (int e = 0; e < ME; ++e) if (e < E) nz[e] = noise[(long long)t * E + e];
   }
-  float l[MAXE], g[MAXE];
+  float l[ME], g[ME];
   float mx = -INFINITY;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) { l[e] = (e < E) ? logits[(long long)t * E + e] : -INFINITY; mx = fmaxf(mx, l[e]); }
+  for (int e = 0; e < ME; ++e) { l[e] = (e < E) ? logits[(long long)t * E + e] : -INFINITY; mx = fmaxf(mx, l[e]); }
   float z = 0.f;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) { g[e] = (e < E) ? expf(l[e] - mx) : 0.f; z += g[e]; }
+  for (int e = 0; e < ME; ++e) { g[e] = (e < E) ? expf(l[e] - mx) : 0.f; z += g[e]; }
   int i1 = 0; float b1 = -INFINITY;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
+  for (int e = 0; e < ME; ++e) {
     g[e] /= z;
     if (e < E) { gates[(long long)t * E + e] = g[e]; if (g[e] > b1) { b1 = g[e]; i1 = e; } }  // first max wins
   }
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict_
   if (k >= 2) {
     int i2 = 0; float b2 = -INFINITY; bool any = false;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
+    for (int e = 0; e < ME; ++e) {
       if (e < E && e != i1) {
         const float v = l[e] + nz[e];
         if (!any || v > b2) { b2 = v; i2 = e; any = true; }
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(256) void gate_top2_kernel(const float* __restrict_
   } else if (prio && have_noise) {          // mask1 * uniform: the priority of this token inside its expert's queue
     float pv = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) if (e == i1) pv = nz[e];
+    for (int e = 0; e < ME; ++e) if (e == i1) pv = nz[e];
     prio[t] = pv;
   }
 }
@@ -207,56 +221,58 @@ __global__ __launch_bounds__(1024) void rts_select_kernel(const int* __restrict_
 // A single-block scan left the chip idle for ~190 us per MoE layer; now: (1) every 512-token block counts its picks per
 // expert and sums its gates, (2) one small block turns the per-block counts into exclusive bases (fixed order, so the
 // gate sums / l_aux are deterministic), (3) every block ranks its tokens with wave ballots and adds its base.
-// part layout (caller scratch, ints): [NB][2*MAXE] counts -> bases, then [NB][MAXE] gate partial sums (as floats).
+// part layout (caller scratch, ints): [NB][2*ME] counts -> bases, then [NB][ME] gate partial sums (as floats).
 #define SCAN_BLK 512
+template <int ME>
 __global__ __launch_bounds__(SCAN_BLK) void moe_count_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
                                                             const float* __restrict__ gates, int* __restrict__ part,
                                                             float* __restrict__ gpart, int T, int E, int k) {
-  __shared__ int wc[SCAN_BLK / 64][2 * MAXE];
-  __shared__ float wg[SCAN_BLK / 64][MAXE];
+  __shared__ int wc[SCAN_BLK / 64][2 * ME];
+  __shared__ float wg[SCAN_BLK / 64][ME];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int t = blockIdx.x * SCAN_BLK + tid;
   const int a = (t < T) ? idx1[t] : -1, b = (t < T && k >= 2) ? idx2[t] : -1;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
+  for (int e = 0; e < ME; ++e) {
     const int c1 = __popcll(__ballot(a == e)), c2 = __popcll(__ballot(b == e));
     const float gs = wave_sum((t < T && e < E) ? gates[(long long)t * E + e] : 0.f);
-    if (lane == 0) { wc[w][e] = c1; wc[w][MAXE + e] = c2; wg[w][e] = gs; }
+    if (lane == 0) { wc[w][e] = c1; wc[w][ME + e] = c2; wg[w][e] = gs; }
   }
   __syncthreads();
-  if (tid < 2 * MAXE) {
+  if (tid < 2 * ME) {
     int s = 0;
 #pragma unroll
     for (int x = 0; x < SCAN_BLK / 64; ++x) s += wc[x][tid];
-    part[blockIdx.x * 2 * MAXE + tid] = s;
-  } else if (tid >= 64 && tid < 64 + MAXE) {
+    part[blockIdx.x * 2 * ME + tid] = s;
+  } else if (tid >= 64 && tid < 64 + ME) {
     float s = 0.f;
 #pragma unroll
     for (int x = 0; x < SCAN_BLK / 64; ++x) s += wg[x][tid - 64];
-    gpart[blockIdx.x * MAXE + tid - 64] = s;
+    gpart[blockIdx.x * ME + tid - 64] = s;
   }
 }
 
-__global__ __launch_bounds__(64) void moe_bases_kernel(int* __restrict__ part, const float* __restrict__ gpart, int nb,
+template <int ME>
+__global__ __launch_bounds__(128) void moe_bases_kernel(int* __restrict__ part, const float* __restrict__ gpart, int nb,
                                                       int* __restrict__ exp_counts, float* __restrict__ gate_sum,
                                                       float* __restrict__ l_aux, int* __restrict__ slots_used, int T, int E,
                                                       int k, int C) {
-  __shared__ int tot[2 * MAXE];
-  __shared__ float gsum[MAXE];
+  __shared__ int tot[2 * ME];
+  __shared__ float gsum[ME];
   const int tid = threadIdx.x;
-  if (tid < 2 * MAXE) {                      // thread = (pick, expert): exclusive prefix over the blocks, in block order
+  if (tid < 2 * ME) {                      // thread = (pick, expert): exclusive prefix over the blocks, in block order
     int run = 0;
-    for (int x = 0; x < nb; ++x) { const int c = part[x * 2 * MAXE + tid]; part[x * 2 * MAXE + tid] = run; run += c; }
+    for (int x = 0; x < nb; ++x) { const int c = part[x * 2 * ME + tid]; part[x * 2 * ME + tid] = run; run += c; }
     tot[tid] = run;
-  } else if (tid >= 32 && tid < 32 + MAXE) {
+  } else if (tid >= 64 && tid < 64 + ME) {
     float s = 0.f;
-    for (int x = 0; x < nb; ++x) s += gpart[x * MAXE + tid - 32];
-    gsum[tid - 32] = s;
+    for (int x = 0; x < nb; ++x) s += gpart[x * ME + tid - 64];
+    gsum[tid - 64] = s;
   }
   __syncthreads();
-  if (tid >= MAXE && tid < 2 * MAXE) {       // second picks queue behind ALL first picks of the same expert
-    const int off = tot[tid - MAXE];
-    for (int x = 0; x < nb; ++x) part[x * 2 * MAXE + tid] += off;
+  if (tid >= ME && tid < 2 * ME) {       // second picks queue behind ALL first picks of the same expert
+    const int off = tot[tid - ME];
+    for (int x = 0; x < nb; ++x) part[x * 2 * ME + tid] += off;
   }
   if (tid == 0 && exp_counts) {
     float la = 0.f;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(64) void moe_bases_kernel(int* __restrict__ part, c
       gate_sum[e] = gsum[e];
       exp_counts[e] = tot[e];
       // capacity slots are filled densely from 0: first picks, then second picks behind them
-      slots_used[e] = min(C, tot[e] + ((k >= 2) ? tot[MAXE + e] : 0));
+      slots_used[e] = min(C, tot[e] + ((k >= 2) ? tot[ME + e] : 0));
       la += (gsum[e] / (float)T) * ((float)tot[e] / (float)T);
     }
     // top2gating: mean(me*ce)*E*E ; top1gating: sum(me*ce)*E — both equal E * sum_e(me*ce)
@@ -272,32 +288,33 @@ __global__ __launch_bounds__(64) void moe_bases_kernel(int* __restrict__ part, c
   }
 }
 
+template <int ME>
 __global__ __launch_bounds__(SCAN_BLK) void moe_rank_kernel(const int* __restrict__ idx1, const int* __restrict__ idx2,
                                                            const int* __restrict__ part, int* __restrict__ loc1,
                                                            int* __restrict__ loc2, int T, int k) {
-  __shared__ int wc[SCAN_BLK / 64][2 * MAXE];
+  __shared__ int wc[SCAN_BLK / 64][2 * ME];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int t = blockIdx.x * SCAN_BLK + tid;
   const int a = (t < T) ? idx1[t] : -1, b = (t < T && k >= 2) ? idx2[t] : -1;
   const unsigned long long below = (1ull << lane) - 1ull;
   int r1 = 0, r2 = 0;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
+  for (int e = 0; e < ME; ++e) {
     const unsigned long long m1 = __ballot(a == e), m2 = __ballot(b == e);
     if (a == e) r1 = __popcll(m1 & below);
     if (b == e) r2 = __popcll(m2 & below);
-    if (lane == 0) { wc[w][e] = __popcll(m1); wc[w][MAXE + e] = __popcll(m2); }
+    if (lane == 0) { wc[w][e] = __popcll(m1); wc[w][ME + e] = __popcll(m2); }
   }
   __syncthreads();
   if (t >= T) return;
-  const int* base = part + blockIdx.x * 2 * MAXE;
+  const int* base = part + blockIdx.x * 2 * ME;
   if (a < 0) { loc1[t] = 0x7fffffff; return; }      // top-1 random token selection dropped this token (k == 1 only)
   int p1 = base[a] + r1;
   for (int x = 0; x < w; ++x) p1 += wc[x][a];
   loc1[t] = p1;
   if (k >= 2) {
-    int p2 = base[MAXE + b] + r2;
-    for (int x = 0; x < w; ++x) p2 += wc[x][MAXE + b];
+    int p2 = base[ME + b] + r2;
+    for (int x = 0; x < w; ++x) p2 += wc[x][ME + b];
     loc2[t] = p2;
   }
 }
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_w_kernel(const bf16_t* __
 }
 
 // gate backward: (dw1, dw2, d l_aux) -> dlogits[T,E]
+template <int ME>
 __global__ __launch_bounds__(256) void moe_gate_bwd_kernel(const float* __restrict__ gates, const int* __restrict__ idx1,
                                                           const int* __restrict__ idx2, const int* __restrict__ slot1,
                                                           const int* __restrict__ slot2, const float* __restrict__ dw1,
@@ -409,10 +427,10 @@ __global__ __launch_bounds__(256) void moe_gate_bwd_kernel(const float* __restri
                                                           int T, int E, int k) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
-  float g[MAXE], dg[MAXE];
+  float g[ME], dg[ME];
   const float dla = d_laux ? d_laux[0] : 0.f;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
+  for (int e = 0; e < ME; ++e) {
     g[e] = (e < E) ? gates[(long long)t * E + e] : 0.f;
     // l_aux = E * sum_e (sum_t gates[t,e]/T) * (count1[e]/T)
     dg[e] = (e < E) ? dla * (float)E * ((float)exp_counts[e] / (float)T) / (float)T : 0.f;
@@ -429,21 +447,22 @@ __global__ __launch_bounds__(256) void moe_gate_bwd_kernel(const float* __restri
       const float common = (u1 * g1 + u2 * g2) / (sum * sum);
       const float d1 = u1 / sum - common, d2 = u2 / sum - common;
 #pragma unroll
-      for (int e = 0; e < MAXE; ++e) { if (k1 && e == e1) dg[e] += d1; if (k2 && e == e2) dg[e] += d2; }
+      for (int e = 0; e < ME; ++e) { if (k1 && e == e1) dg[e] += d1; if (k2 && e == e2) dg[e] += d2; }
     }
   } else {
     const float u1 = dw1[t];
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) if (k1 && e == e1) dg[e] += u1;
+    for (int e = 0; e < ME; ++e) if (k1 && e == e1) dg[e] += u1;
   }
   float dot = 0.f;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) dot += g[e] * dg[e];
+  for (int e = 0; e < ME; ++e) dot += g[e] * dg[e];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) if (e < E) dlogits[(long long)t * E + e] = g[e] * (dg[e] - dot);
+  for (int e = 0; e < ME; ++e) if (e < E) dlogits[(long long)t * E + e] = g[e] * (dg[e] - dot);
 }
 
 // dx[t] = d_in[slot1(t)] + d_in[slot2(t)] + bf16( sum_e dlogits[t,e] * wg[e] )   (dispatch is a copy)
+template <int ME>
 __global__ __launch_bounds__(256) void moe_dispatch_bwd_kernel(const bf16_t* __restrict__ d_in, const int* __restrict__ slot1,
                                                               const int* __restrict__ slot2, const float* __restrict__ dlogits,
                                                               const float* __restrict__ wg, bf16_t* __restrict__ dx,
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(256) void moe_dispatch_bwd_kernel(const bf16_t* __r
     for (int k = 0; k < 8; ++k) r[k] = 0.f;
     if (dlogits) {
 #pragma unroll
-      for (int e = 0; e < MAXE; ++e) {
+      for (int e = 0; e < ME; ++e) {
         if (e < E) {
           const float dl = dlogits[t * E + e];
           const f32x4 a = *(const f32x4*)(wg + (long long)e * H + c);
@@ -493,16 +512,17 @@ __global__ __launch_bounds__(256) void moe_dispatch_bwd_kernel(const bf16_t* __r
 #define WG_SLAB 64
 __global__ __launch_bounds__(256) void router_wgrad_partial_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dlogits,
                                                                   float* __restrict__ partial, int T, int H, int E) {
-  __shared__ float dl[WG_SLAB * MAXE];
+  __shared__ float dl[WG_SLAB * EG];
   const int h0 = (blockIdx.x * 256 + threadIdx.x) * 8;
   const int slab = blockIdx.y;
+  const int eb = blockIdx.z * EG, En = min(E - eb, EG);         // this block's group of 8 experts
   const int lo = slab * WG_SLAB, hi = min(lo + WG_SLAB, T);
-  for (int i = threadIdx.x; i < (hi - lo) * E; i += 256) dl[(i / E) * MAXE + (i % E)] = dlogits[(long long)lo * E + i];
+  for (int i = threadIdx.x; i < (hi - lo) * En; i += 256) dl[(i / En) * EG + (i % En)] = dlogits[(long long)(lo + i / En) * E + eb + (i % En)];
   __syncthreads();
   if (h0 >= H) return;
-  float acc[MAXE][8];
+  float acc[EG][8];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e)
+  for (int e = 0; e < EG; ++e)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
 #pragma unroll 4
@@ -512,17 +532,17 @@ __global__ __launch_bounds__(256) void router_wgrad_partial_kernel(const bf16_t*
 #pragma unroll
     for (int w = 0; w < 4; ++w) { xf[2 * w] = bflo(xv[w]); xf[2 * w + 1] = bfhi(xv[w]); }
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e)
-      if (e < E) {
-        const float d = dl[(t - lo) * MAXE + e];
+    for (int e = 0; e < EG; ++e)
+      if (e < En) {
+        const float d = dl[(t - lo) * EG + e];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[e][j] += d * xf[j];
       }
   }
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e)
-    if (e < E) {
-      float* pp = partial + ((long long)slab * E + e) * H + h0;
+  for (int e = 0; e < EG; ++e)
+    if (e < En) {
+      float* pp = partial + ((long long)slab * E + eb + e) * H + h0;
       *(f32x4*)pp = (f32x4){acc[e][0], acc[e][1], acc[e][2], acc[e][3]};
       *(f32x4*)(pp + 4) = (f32x4){acc[e][4], acc[e][5], acc[e][6], acc[e][7]};
     }
@@ -611,20 +631,21 @@ __global__ __launch_bounds__(256) void residual_mix_bwd_kernel(const bf16_t* __r
   }
 }
 // dx[t, :] = sum_e dlogits[t, e] * w[e, :]   (the input gradient of a tiny fp32 linear: router-sized heads)
+template <int ME>
 __global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w,
                                                                 bf16_t* __restrict__ dx, int T, int H, int E) {
   const int lane = threadIdx.x & 63;
   const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
-  float d[MAXE];
+  float d[ME];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) d[e] = (e < E) ? dl[t * E + e] : 0.f;
+  for (int e = 0; e < ME; ++e) d[e] = (e < E) ? dl[t * E + e] : 0.f;
   for (int c = lane * 8; c < H; c += 512) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
+    for (int e = 0; e < ME; ++e) {
       if (e < E) {
         const f32x4 w0 = *(const f32x4*)(w + (long long)e * H + c), w1 = *(const f32x4*)(w + (long long)e * H + c + 4);
 #pragma unroll
@@ -640,7 +661,7 @@ extern "C" {
 int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, int H, int E, hipStream_t stream) {
   if (!x || !wg || !logits || T < 0 || H <= 0 || (H & 7) || E <= 0 || E > MAXE) return LMOD_EINVAL;
   if (T == 0) return LMOD_OK;
-  hipLaunchKernelGGL(router_fwd_kernel, dim3((T + 15) / 16), dim3(256), 0, stream, (const bf16_t*)x, wg, logits, T, H, E);
+  hipLaunchKernelGGL(router_fwd_kernel, dim3((T + 15) / 16, (E + EG - 1) / EG), dim3(256), 0, stream, (const bf16_t*)x, wg, logits, T, H, E);
   return lmod_launch_status();
 }
 
@@ -651,7 +672,8 @@ int lmod_moe_router_fwd(const void* x, const float* wg, float* logits, int T, in
 //   noise_out (nullable, [T,E]): receives the drawn noise.
 // Outputs: gates[T,E] f32; idx1/idx2/slot1/slot2 [T] i32; w1/w2 [T] f32; slot_token [E*C] i32 (-1 empty);
 // slot_w [E*C] f32; exp_counts [E] i32; gate_sum [E] f32; l_aux [1] f32.
-// scratch: 4*T + 24*ceil(T/512) i32 (loc1, loc2, rts priorities / kept picks, per-block pick counts / bases, gate partials).
+// scratch: 4*T + 3*ME*ceil(T/512) i32, ME = 8 / 16 / 32 expert slots for E <= 8 / 16 / 32 (loc1, loc2, rts priorities / kept
+// picks, per-block pick counts / bases, gate partials).
 int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, int C, float* gates, int* idx1,
                   int* idx2, int* slot1, int* slot2, float* w1, float* w2, int* slot_token, float* slot_w,
                   int* exp_counts, float* gate_sum, float* l_aux, int* slots_used, int* scratch, int noise_mode,
@@ -664,23 +686,25 @@ int lmod_moe_gate(const float* logits, const float* noise, int T, int E, int k, 
   float* prio = (float*)(scratch + 2 * (long long)T);
   int* keep = scratch + 3 * (long long)T;
   const int nb = (T + SCAN_BLK - 1) / SCAN_BLK;
-  int* part = scratch + 4 * (long long)T;                       // [nb][2*MAXE] ints
-  float* gpart = (float*)(part + (long long)nb * 2 * MAXE);     // [nb][MAXE] floats
+  int* part = scratch + 4 * (long long)T;                       // [nb][2*ME] ints
+  float* gpart = (float*)(part + (long long)nb * 2 * me_of(E)); // [nb][ME] floats
   const bool rts = (k == 1) && (noise != nullptr || noise_mode == 2);
-  hipLaunchKernelGGL(gate_top2_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2, T, E, k,
-                     noise_mode, seed, offset, noise_out, rts ? prio : (float*)nullptr);
-  hipLaunchKernelGGL(moe_count_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, gates, part, gpart, T, E, k);
-  hipLaunchKernelGGL(moe_bases_kernel, dim3(1), dim3(64), 0, stream, part, gpart, nb, exp_counts, gate_sum, l_aux, slots_used,
-                     T, E, k, C);
   const int* rank_idx = idx1;
-  if (rts) {       // survivors of the random token selection, then their token-order positions (statistics stay as above)
-    hipLaunchKernelGGL(rts_select_kernel, dim3(E), dim3(1024), 0, stream, idx1, prio, keep, T, C);
-    hipLaunchKernelGGL(moe_count_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, keep, idx2, gates, part, gpart, T, E, k);
-    hipLaunchKernelGGL(moe_bases_kernel, dim3(1), dim3(64), 0, stream, part, gpart, nb, (int*)nullptr, (float*)nullptr,
-                       (float*)nullptr, (int*)nullptr, T, E, k, C);
-    rank_idx = keep;
-  }
-  hipLaunchKernelGGL(moe_rank_kernel, dim3(nb), dim3(SCAN_BLK), 0, stream, rank_idx, idx2, part, loc1, loc2, T, k);
+  ME_DISPATCH(E, {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gate_top2_kernel<ME>), dim3((T + 255) / 256), dim3(256), 0, stream, logits, noise, gates, idx1, idx2,
+                       T, E, k, noise_mode, seed, offset, noise_out, rts ? prio : (float*)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_count_kernel<ME>), dim3(nb), dim3(SCAN_BLK), 0, stream, idx1, idx2, gates, part, gpart, T, E, k);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_bases_kernel<ME>), dim3(1), dim3(128), 0, stream, part, gpart, nb, exp_counts, gate_sum, l_aux,
+                       slots_used, T, E, k, C);
+    if (rts) {     // survivors of the random token selection, then their token-order positions (statistics stay as above)
+      hipLaunchKernelGGL(rts_select_kernel, dim3(E), dim3(1024), 0, stream, idx1, prio, keep, T, C);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_count_kernel<ME>), dim3(nb), dim3(SCAN_BLK), 0, stream, keep, idx2, gates, part, gpart, T, E, k);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_bases_kernel<ME>), dim3(1), dim3(128), 0, stream, part, gpart, nb, (int*)nullptr,
+                         (float*)nullptr, (float*)nullptr, (int*)nullptr, T, E, k, C);
+      rank_idx = keep;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_rank_kernel<ME>), dim3(nb), dim3(SCAN_BLK), 0, stream, rank_idx, idx2, part, loc1, loc2, T, k);
+  });
   if (hipMemsetAsync(slot_token, 0xFF, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   if (hipMemsetAsync(slot_w, 0, (size_t)E * C * 4, stream) != hipSuccess) return LMOD_ELAUNCH;
   hipLaunchKernelGGL(moe_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, loc1, loc2,
@@ -717,8 +741,8 @@ int lmod_moe_gate_bwd(const float* gates, const int* idx1, const int* idx2, cons
     return LMOD_EINVAL;
   if (k == 2 && (!idx2 || !slot2 || !dw2)) return LMOD_EINVAL;
   if (T == 0) return LMOD_OK;
-  hipLaunchKernelGGL(moe_gate_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2, slot1, slot2,
-                     dw1, dw2, exp_counts, d_laux, dlogits, T, E, k);
+  ME_DISPATCH(E, hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_gate_bwd_kernel<ME>), dim3((T + 255) / 256), dim3(256), 0, stream, gates, idx1, idx2,
+                                    slot1, slot2, dw1, dw2, exp_counts, d_laux, dlogits, T, E, k));
   return lmod_launch_status();
 }
 
@@ -726,8 +750,8 @@ int lmod_moe_dispatch_bwd(const void* d_in, const int* slot1, const int* slot2, 
                           void* dx, int T, int H, int E, hipStream_t stream) {
   if (!d_in || !slot1 || !dx || T < 0 || H <= 0 || (H & 7) || (dlogits && (!wg || E <= 0 || E > MAXE))) return LMOD_EINVAL;
   if (T == 0) return LMOD_OK;
-  hipLaunchKernelGGL(moe_dispatch_bwd_kernel, dim3(grid_for((long long)T * (H >> 3))), dim3(256), 0, stream,
-                     (const bf16_t*)d_in, slot1, slot2, dlogits, wg, (bf16_t*)dx, (long long)T, H, E);
+  ME_DISPATCH(dlogits ? E : 1, hipLaunchKernelGGL(HIP_KERNEL_NAME(moe_dispatch_bwd_kernel<ME>), dim3(grid_for((long long)T * (H >> 3))), dim3(256), 0,
+                                                  stream, (const bf16_t*)d_in, slot1, slot2, dlogits, wg, (bf16_t*)dx, (long long)T, H, E));
   return lmod_launch_status();
 }
 
@@ -737,8 +761,8 @@ int lmod_moe_router_wgrad(const void* x, const float* dlogits, float* dwg, float
   if (!x || !dlogits || !dwg || !workspace || T < 0 || H <= 0 || (H & 7) || E <= 0 || E > MAXE) return LMOD_EINVAL;
   if (T == 0) return LMOD_OK;
   const int nslab = (T + WG_SLAB - 1) / WG_SLAB;
-  hipLaunchKernelGGL(router_wgrad_partial_kernel, dim3((H / 8 + 255) / 256, nslab), dim3(256), 0, stream, (const bf16_t*)x,
-                     dlogits, workspace, T, H, E);
+  hipLaunchKernelGGL(router_wgrad_partial_kernel, dim3((H / 8 + 255) / 256, nslab, (E + EG - 1) / EG), dim3(256), 0, stream,
+                     (const bf16_t*)x, dlogits, workspace, T, H, E);
   hipLaunchKernelGGL(router_wgrad_reduce_kernel, dim3((E * H + 63) / 64), dim3(1024), 0, stream, workspace, dwg, nslab,
                      E * H, accumulate);
   return lmod_launch_status();
@@ -768,7 +792,8 @@ int lmod_small_linear_dgrad(const float* dlogits, const float* w, void* dx, int 
   if (T < 0 || H <= 0 || (H & 7) || E <= 0 || E > MAXE) return LMOD_EINVAL;
   if (T == 0) return LMOD_OK;
   if (!dlogits || !w || !dx || ((uintptr_t)w & 15)) return LMOD_EINVAL;
-  hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, dlogits, w, (bf16_t*)dx, T, H, E);
+  ME_DISPATCH(E, hipLaunchKernelGGL(HIP_KERNEL_NAME(small_linear_dgrad_kernel<ME>), dim3((T + 3) / 4), dim3(256), 0, stream, dlogits, w,
+                                    (bf16_t*)dx, T, H, E));
   return lmod_launch_status();
 }
 

@@ -395,7 +395,8 @@ def moe_gate(logits, k, C, noise=None, seed=None, offset=0, want_noise=False):
     st.slot_token = torch.empty(E * C, **i32); st.slot_w = torch.empty(E * C, **f32)
     st.exp_counts = torch.empty(E, **i32); st.gate_sum = torch.empty(E, **f32); st.l_aux = torch.empty(1, **f32)
     st.slots_used = torch.empty(E, **i32)
-    scratch = torch.empty(4 * T + 24 * ((T + 511) // 512), **i32)
+    me = 8 if E <= 8 else (16 if E <= 16 else 32)          # expert slots of the routing kernels' instantiation (csrc/moe.hip)
+    scratch = torch.empty(4 * T + 3 * me * ((T + 511) // 512), **i32)
     mode = 0 if (noise is not None or seed is None) else (1 if k == 2 else 2)
     st.noise = torch.empty((T, E), **f32) if (mode and want_noise) else None
     call("lmod_moe_gate", ptr(logits), ptr(noise), T, E, k, C, ptr(st.gates), ptr(st.idx1), ptr(st.idx2),

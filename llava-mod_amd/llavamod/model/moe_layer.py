@@ -52,8 +52,9 @@ class MoE(nn.Module):
             raise ValueError("Only top-1 and top-2 gatings are supported (DeepSpeed 0.9.5 TopKGate)")
         if num_experts % ep_size:
             raise ValueError(f"Number of experts ({num_experts}) should be divisible by expert parallel size ({ep_size})")
-        if num_experts > 8:
-            raise NotImplementedError("the routing kernels are compiled for <= 8 experts")
+        if num_experts > 32:
+            # csrc/moe.hip keeps one value per expert in registers: instantiations for 8 / 16 / 32 slots (LMOD_MAX_EXPERTS)
+            raise NotImplementedError("the routing kernels are compiled for <= 32 experts per layer")
         self.hidden_size, self.num_experts, self.ep_size, self.k = hidden_size, num_experts, ep_size, k
         self.capacity_factor, self.eval_capacity_factor, self.min_capacity = capacity_factor, eval_capacity_factor, min_capacity
         self.use_rts = use_rts

@@ -78,12 +78,16 @@ def freeze_like_d2s(student: LlavaOracle):
     return student
 
 
-def mimic_step(student, teacher, batch, loss_type="only_kd", moe_loss_enable=True, align_vocab=losses.ALIGN_VOCAB):
-    """One AlignTrainer.training_step worth of math: teacher fwd (no_grad), student fwd, loss, backward."""
+def mimic_step(student, teacher, batch, loss_type="only_kd", moe_loss_enable=True, align_vocab=losses.ALIGN_VOCAB,
+               distill_all_tokens=False):
+    """One AlignTrainer.training_step worth of math: teacher fwd (no_grad), student fwd, loss, backward.
+    distill_all_tokens: `--distill_all_tokens` (config/args.py:110; align_trainer.py:516-520: the KD mask is all ones,
+    padding rows included)."""
     with torch.no_grad():
         t_out = teacher(**batch)
     s_out = student(**batch)
-    loss, logs = losses.mimic_loss(s_out, t_out, loss_type, moe_loss_enable, align_vocab=align_vocab)
+    loss, logs = losses.mimic_loss(s_out, t_out, loss_type, moe_loss_enable, distill_all_tokens=distill_all_tokens,
+                                   align_vocab=align_vocab)
     loss.backward()
     return loss.detach(), logs, s_out, t_out
 

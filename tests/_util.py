@@ -53,13 +53,14 @@ def moe_args(dec_cfg, train_modules=D2S_TRAIN_MODULES):
                            router_aux_loss_coef=dec_cfg.router_aux_loss_coef, num_experts=[dec_cfg.num_experts])
 
 
-def build_hip_pair(student_sd, teacher_sd, sc, tc, vc, device="cuda"):
-    """HIP student (up-cycled MoE) + dense teacher carrying the oracle's weights (cast to bf16; router fp32)."""
+def build_hip_pair(student_sd, teacher_sd, sc, tc, vc, device="cuda", margs=None):
+    """HIP student (up-cycled MoE) + dense teacher carrying the oracle's weights (cast to bf16; router fp32).
+    margs: the `model_args` handed to `initialize_moe_modules` (default: explicit layer indices from `sc`)."""
     from llavamod.model import LLaVAMoDQwen2ForCausalLM, LlavaQwen2ForCausalLM
     scfg, _ = hip_configs(sc, vc, moe=True)
     tcfg, _ = hip_configs(tc, vc, moe=False)
     student = LLaVAMoDQwen2ForCausalLM(scfg, device=device)
-    student.initialize_moe_modules(moe_args(sc))
+    student.initialize_moe_modules(margs if margs is not None else moe_args(sc))
     for p in student.get_model().mm_projector.parameters():       # initialize_vision_modules re-enables these
         p.requires_grad = True
     teacher = LlavaQwen2ForCausalLM(tcfg, device=device)

@@ -11,6 +11,7 @@ routing (`_twin_run`, `_check_grads_floor`).  No flat gradient / logit bound is 
 """
 import os
 import sys
+from types import SimpleNamespace
 
 import pytest
 import torch
@@ -222,7 +223,7 @@ def _routing_report(student, o_student):
     return agree / max(1, total), worst_margin
 
 
-def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97):
+def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97, distill_all=False, margs=None):
     """One mimic step vs the oracle on the same seeded inputs.  The router argmax is discontinuous: bf16 activations can
     break a near-tie differently from the fp32 oracle for a few tokens.  So the case (1) requires >= `min_agree` of the routing
     decisions to agree and every disagreement to be a near-tie, then (2) re-runs the oracle with the GPU path's expert picks
@@ -231,21 +232,21 @@ def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97):
     from llavamod.train.align_trainer import AlignTrainer
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     o_student, o_teacher = _seeded_pair(seed, sc, tc, vc)
-    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV, margs=margs)
     for m, nz in zip(student.moe_layers(), noises):
         m.deterministic = nz is None
         m.gate_noise = nz
     GradBuffer(student)
     hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
     Va = min(olosses.ALIGN_VOCAB, sc.vocab_size, tc.vocab_size)
-    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False,
+    tr = AlignTrainer(student, teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=distill_all,
                                                                loss_type="kd_lm", moe_loss_enable=True))(), align_vocab=Va)
     student.train()
     loss, outs = tr.compute_loss(student, hb, return_outputs=True)
     loss.backward()
     # (1) free-running oracle: routing agreement
     o_student.train(); o_teacher.eval(); o_student.set_gate_noise(noises)
-    mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va)
+    mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va, distill_all_tokens=distill_all)
     frac, margin = _routing_report(student, o_student)
     assert frac >= min_agree, frac
     assert margin <= 2e-2, margin
@@ -253,7 +254,7 @@ def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97):
     o_student.zero_grad()
     for hm, om in zip(student.moe_layers(), _oracle_moes(o_student)):
         om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
-    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va)
+    loss_o, logs_o, _, _ = mimic_step(o_student, o_teacher, batch, loss_type="kd_lm", align_vocab=Va, distill_all_tokens=distill_all)
     for k in ("loss", "loss/align", "loss/moe_balance", "loss/lm"):
         got, exp = float(outs[k]), float(logs_o[k])
         assert abs(got - exp) <= 1e-3 * abs(exp), (k, got, exp)
@@ -265,12 +266,12 @@ def _mimic_parity_case(vc, sc, tc, seed, batch, noises, tag, min_agree=0.97):
     tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(noises)
     for hm, om in zip(student.moe_layers(), _oracle_moes(tw_s)):
         om.forced = (hm.last_state.idx1.cpu(), hm.last_state.idx2.cpu())
-    _, logs_f, _, _ = mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=Va)
+    _, logs_f, _, _ = mimic_step(tw_s, tw_t, _bf16_batch(batch), loss_type="kd_lm", align_vocab=Va, distill_all_tokens=distill_all)
     fgrads = {U.oracle_to_hip_key(n): p.grad for n, p in tw_s.named_parameters() if p.grad is not None}
     worst = _check_grads_floor(hgrads, ograds, fgrads, tag)
     print(f"{tag}: routing agreement {frac * 100:.1f} %; loss floor "
           f"{abs(float(logs_f['loss']) - float(logs_o['loss'])) / abs(float(logs_o['loss'])):.2e}")
-    return worst
+    return SimpleNamespace(worst=worst, student=student, teacher=teacher, logs_o=logs_o)
 
 
 @pytest.mark.parametrize("ragged,noise", [(False, True), (True, False)])
