@@ -8,7 +8,17 @@
  * Conventions: raw device pointers, explicit dims / leading dimensions (in ELEMENTS), the HIP
  * stream to enqueue on, caller-owned outputs and workspaces.  Every function only enqueues work
  * (no allocation, no synchronisation) and returns 0 on success or a negative LMOD_E* code; it
- * never throws.  bf16 tensors are `void*` to raw uint16 bit patterns.  No global mutable state.
+ * never throws.  bf16 tensors are `void*` to raw uint16 bit patterns.
+ *
+ * State.  No entry point keeps data between calls: every buffer, workspace and counter is the caller's.  What the library
+ * does keep, process-wide, is launch CONFIGURATION, all of it idempotent and safe under concurrent first use:
+ *   - per kernel instance, a flag "dynamic-LDS attribute already set" (hipFuncSetAttribute is issued once);
+ *   - the compute-unit count per device id (the persistent GEMM grid is one workgroup per CU of the CURRENT device);
+ *   - the communicator handles behind lmod_comm_* (owned by the caller through their opaque pointers);
+ *   - measurement switches from the environment, documented beside their readers in csrc/ — read once at first use:
+ *     LMOD_GEMM_WAVES, LMOD_ATTN_FWD, LMOD_ATTN_BWD, LMOD_WGRAD_SPLIT; read at every launch (so that one test process can
+ *     run both arms of an A/B): LMOD_GEMM_PERSIST, LMOD_GEMM_PERSIST_ROUNDS, LMOD_GEMM_KV4, LMOD_GEMM_TN4, LMOD_GEMM_TILE.
+ *     Unset, they select the shipped routing; none changes results (each pair of arms is bit-identical, tests/test_kernels_gpu.py).
  */
 #ifndef LMOD_HIP_H
 #define LMOD_HIP_H

@@ -2537,14 +2537,23 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // (MODE 4) than on the 4-wave kernel.  That epilogue must NOT sit inside gemm_256_kernel<0>: there it cost the plain GEMM
 // 22 % (1390 -> 1075 TF, found by timing library builds of three commits in one process, tools/gemm_ab.py).
 // LMOD_GEMM_WAVES=4 runs the 4-wave kernel everywhere (A/B runs).
+// Process-wide state of the launchers (all of it, see include/lmod_hip.h "State"): this routing switch, read ONCE (C++11 static
+// initialisation: thread-safe); the per-kernel-instance "LDS attribute set" flags (idempotent: a race only repeats the call); the CU
+// count per device id; and the A/B environment switches LMOD_GEMM_PERSIST / _PERSIST_ROUNDS / _KV4, read per launch.
 static int gemm_waves() {
-  static int w = -1;
-  if (w < 0) { const char* e = getenv("LMOD_GEMM_WAVES"); w = e ? atoi(e) : 0; if (w != 8 && w != 4 && w != 44) w = 0; }      // 44: default routing + the 4-wave MODE 4 / 6 instantiations (A/B)
+  static const int w = [] {
+    const char* e = getenv("LMOD_GEMM_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return (v == 8 || v == 4 || v == 44) ? v : 0;       // 44: default routing + the 4-wave MODE 4 / 6 instantiations (A/B)
+  }();
   return w;
 }
 template <typename KT>
 static void allow_lds(KT kern, int bytes, bool& done) {      // once per kernel instance, not once per launch
-  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done = true; }
+  if (!__atomic_load_n(&done, __ATOMIC_ACQUIRE)) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    __atomic_store_n(&done, true, __ATOMIC_RELEASE);
+  }
 }
 // one launch of the 8-wave kernel: the K64 instantiation when every reduction length of the launch is a multiple of 64
 static inline bool k64_ok(const GemmP& p) { return (p.K & 63) == 0 && !p.k_valid; }      // (split-K chunks are multiples of 64)
@@ -2564,9 +2573,19 @@ static void launch_256x(const GemmP& p, long long nwg, hipStream_t stream) {
 #ifndef G4_PERSIST_DEFAULT
 #define G4_PERSIST_DEFAULT 1
 #endif
+// Compute units of the CURRENT device (the persistent grid is one workgroup per CU), cached per device id: a process that drives
+// several devices, or a partitioned one, sizes each device's walk from that device's own count.  (A CU-masked stream still gets
+// the full count: the tile loop keeps the results correct, the walk is merely longer per resident workgroup.)
 static int gemm_cus() {
-  static int n = 0;
-  if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; if (n <= 0) n = 256; }
+  static int cus[64];                                  // 0 = not asked yet; written once per device id (idempotent)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+  if (!n) {
+    hipDeviceProp_t pr;
+    n = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+  }
   return n;
 }
 static bool gemm_persist(const GemmP& p, long long nwg) {

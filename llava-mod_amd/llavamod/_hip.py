@@ -115,8 +115,12 @@ def stream():
 TRACE = None
 
 
-def call(name, *args):
-    """Invoke `name` on the current torch stream; raise on a non-zero status."""
+UNSUPPORTED = -3
+
+
+def call(name, *args, allow=()):
+    """Invoke `name` on the current torch stream; raise on a non-zero status (statuses listed in `allow` are returned instead:
+    a caller that has a documented two-step form for LMOD_EUNSUPPORTED shapes passes `allow=(UNSUPPORTED,)`)."""
     lib = load()
     if TRACE is not None and name in TRACE["names"]:
         import torch
@@ -127,5 +131,6 @@ def call(name, *args):
         TRACE["rows"].append((name, tuple(a if isinstance(a, int) else (0 if a is None else 1) for a in args), e0, e1))
     else:
         rc = getattr(lib, name)(*args, stream())
-    if rc != 0:
+    if rc != 0 and rc not in allow:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+    return rc

@@ -28,15 +28,82 @@ def _normalise(key):
     return key
 
 
-def save_checkpoint(model, out_dir, max_shard_bytes=5 << 30, projector_file=True):
+_EXPERT_KEY = re.compile(r"(.*)\.deepspeed_moe\.experts\.deepspeed_experts\.(\d+)\.(.*)")
+
+
+def _dist_rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def expert_parallel_layout(model):
+    """{MoE module name: (ep_size, local experts, this rank's index in its expert-parallel group)} for the layers whose experts
+    are sharded over ranks (`ep_size` > 1).  A rank's `deepspeed_experts.{i}` is then GLOBAL expert `ep_rank * n_local + i`
+    (DeepSpeed numbers them the same way: `global_expert_id = ep_rank * num_local_experts + local_id`)."""
+    from .model.moe_layer import MoE
+    rank, _ = _dist_rank_world()
+    return {n: (m.ep_size, m.num_local_experts, rank % m.ep_size) for n, m in model.named_modules()
+            if isinstance(m, MoE) and m.ep_size > 1}
+
+
+def _atomic(write, path):
+    """`write(tmp)` then rename: a reader (or a crash) never sees a half-written shard / index / projector file."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    write(tmp)
+    os.replace(tmp, path)
+
+
+def full_state_dict(model, writer_rank=0):
+    """The model's state dict on the host with GLOBAL expert names.  Without expert parallelism this is `model.state_dict()`.
+    With `ep_size` > 1 a rank only holds `n_local` of a layer's experts under local indices: the ranks of the WRITER's
+    expert-parallel group all-gather every expert tensor (a collective: each of them must call this) and the result carries
+    `deepspeed_experts.{ep_rank * n_local + i}` — the layout an `ep_size` = 1 model (and the reference's FineTune / Eval classes)
+    load.  Returns None on ranks that are not the writer."""
+    import torch.distributed as dist
+    rank, world = _dist_rank_world()
+    layout = expert_parallel_layout(model)
+    own = model.state_dict()
+    if not layout:
+        return {k: v.detach().to("cpu").contiguous() for k, v in own.items()} if rank == writer_rank else None
+    ep = next(iter(layout.values()))[0]
+    if rank // ep != writer_rank // ep:          # another replica of the same experts: nothing to contribute
+        return None
+    from .engine import expert_parallel_group
+    group = expert_parallel_group(ep)
+    out = {}
+    for k, v in own.items():
+        m = _EXPERT_KEY.match(k)
+        lay = layout.get(m.group(1)) if m else None
+        if lay is None:
+            if rank == writer_rank:
+                out[k] = v.detach().to("cpu").contiguous()
+            continue
+        ep_size, n_local, _ = lay
+        parts = [torch.empty_like(v) for _ in range(ep_size)]
+        dist.all_gather(parts, v.detach().contiguous(), group=group)
+        if rank == writer_rank:
+            for r, t in enumerate(parts):
+                out[f"{m.group(1)}.deepspeed_moe.experts.deepspeed_experts.{r * n_local + int(m.group(2))}.{m.group(3)}"] = \
+                    t.to("cpu").contiguous()
+    return out if rank == writer_rank else None
+
+
+def save_checkpoint(model, out_dir, max_shard_bytes=5 << 30, projector_file=True, writer_rank=0):
     """Write `model-XXXXX-of-YYYYY.safetensors` + index (HF layout) and, like the reference's trainer, the projector
-    weights alone as `mm_projector.bin`.  Returns the list of files written."""
-    os.makedirs(out_dir, exist_ok=True)
+    weights alone as `mm_projector.bin`; every file through a temporary name + rename.  ONE rank writes (`writer_rank`, the
+    global rank: on a multi-node run every node's local rank 0 would otherwise race on the same files).  Expert-parallel
+    models: collective over the writer's expert-parallel group, experts saved under global indices (`full_state_dict`).
+    Returns the list of files written (empty on the other ranks)."""
     from .engine import fused_weights_of
     for fw in fused_weights_of(model):          # orders this stream after any optimizer update still in flight
         if fw.w is not None:
             fw.ensure()
-    sd = {k: v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
+    sd = full_state_dict(model, writer_rank)
+    if sd is None:
+        return []
+    os.makedirs(out_dir, exist_ok=True)
     shards, cur, size = [], {}, 0
     for k, v in sd.items():
         n = v.numel() * v.element_size()
@@ -48,17 +115,20 @@ def save_checkpoint(model, out_dir, max_shard_bytes=5 << 30, projector_file=True
     files, weight_map = [], {}
     for i, sh in enumerate(shards):
         name = "model.safetensors" if len(shards) == 1 else f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
-        save_file(sh, os.path.join(out_dir, name), metadata={"format": "pt"})
+        _atomic(lambda t, sh=sh: save_file(sh, t, metadata={"format": "pt"}), os.path.join(out_dir, name))
         files.append(name)
         weight_map.update({k: name for k in sh})
     if len(shards) > 1:
         total = sum(v.numel() * v.element_size() for v in sd.values())
-        json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, open(os.path.join(out_dir, INDEX), "w"), indent=1)
+        def write_index(t):
+            with open(t, "w") as f:
+                json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
+        _atomic(write_index, os.path.join(out_dir, INDEX))
         files.append(INDEX)
     if projector_file:
         proj = {k: v for k, v in sd.items() if "mm_projector" in k}
         if proj:
-            torch.save(proj, os.path.join(out_dir, "mm_projector.bin"))
+            _atomic(lambda t: torch.save(proj, t), os.path.join(out_dir, "mm_projector.bin"))
             files.append("mm_projector.bin")
     return files
 
@@ -105,24 +175,36 @@ def load_checkpoint(model, path, strict=True, ignore_prefixes=(), state=None):
     src = {k: v for k, v in src.items() if not k.startswith(tuple(ignore_prefixes))} if ignore_prefixes else src
     own = model.state_dict()
     used, missing, plan = set(), [], []
+    layout = expert_parallel_layout(model)      # expert-parallel model: local expert i is the checkpoint's global ep_rank*n_local+i
+    ep_owned = set()
     for k, t in own.items():                 # validate everything BEFORE touching the model: a failed load leaves it intact
         if ignore_prefixes and k.startswith(tuple(ignore_prefixes)):
             continue
-        v = src.get(k)
+        m = _EXPERT_KEY.match(k) if layout else None
+        if m and m.group(1) in layout:
+            ep_size, n_local, ep_rank = layout[m.group(1)]
+            gk = f"{m.group(1)}.deepspeed_moe.experts.deepspeed_experts.{ep_rank * n_local + int(m.group(2))}.{m.group(3)}"
+            for r in range(ep_size * n_local):   # the other ranks' experts of this layer are not "unexpected" here
+                ep_owned.add(f"{m.group(1)}.deepspeed_moe.experts.deepspeed_experts.{r}.{m.group(3)}")
+            v = src.get(gk)
+            if v is not None:
+                used.add(gk)
+        else:
+            v = src.get(k)
+            if v is not None:
+                used.add(k)
         if v is None:
             m = re.match(r"(.*\.mlp\.)deepspeed_moe\.experts\.deepspeed_experts\.\d+\.(.*)", k)
             if m and (m.group(1) + m.group(2)) in src:
                 v = src[m.group(1) + m.group(2)]
                 used.add(m.group(1) + m.group(2))
-        else:
-            used.add(k)
         if v is None:
             missing.append(k)
             continue
         if tuple(v.shape) != tuple(t.shape):
             raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model shape {tuple(t.shape)}")
         plan.append((t, v))
-    unexpected = sorted(set(src) - used)
+    unexpected = sorted(set(src) - used - ep_owned)
     if strict and (missing or unexpected):
         raise KeyError(f"missing {missing[:5]}{'...' if len(missing) > 5 else ''}, "
                        f"unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")

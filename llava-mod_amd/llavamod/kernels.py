@@ -7,6 +7,7 @@ import os
 
 import torch
 
+from . import _hip
 from ._hip import call, ptr
 
 BF16 = torch.bfloat16
@@ -68,8 +69,13 @@ def gemm_nt_res(x, w, res, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=BF16)
-    call("lmod_gemm_bf16_nt_res", ptr(x), ptr(w), ptr(out), None, ptr(res), M, N, Kd, x.stride(0), w.stride(0), out.stride(0),
-         res.stride(0))
+    rc = call("lmod_gemm_bf16_nt_res", ptr(x), ptr(w), ptr(out), None, ptr(res), M, N, Kd, x.stride(0), w.stride(0), out.stride(0),
+              res.stride(0), allow=(_hip.UNSUPPORTED,))
+    if rc == _hip.UNSUPPORTED:
+        # a shape (or a build: G4_ASM=0, LMOD_GEMM_WAVES) the residual-epilogue kernel does not take, although `gemm_res_fusable`
+        # — a mirror of the library's test — said yes: the header's two-step form, same roundings (bf16(res + bf16(acc)))
+        gemm_nt(x, w, out=out)
+        add(out, res if res.is_contiguous() else res.contiguous(), out=out)
     return out
 
 

@@ -316,11 +316,15 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
             json.dump(cfg, f, indent=1)
         os.replace(tmp, os.path.join(save_directory, "config.json"))
 
-    def save_pretrained(self, save_directory, max_shard_bytes=5 << 30):
-        """config.json + HF-layout safetensors shards (+ mm_projector.bin), loadable by `from_pretrained`."""
-        from ...checkpoint import save_checkpoint
-        self.save_config(save_directory)
-        return save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes)
+    def save_pretrained(self, save_directory, max_shard_bytes=5 << 30, writer_rank=0):
+        """config.json + HF-layout safetensors shards (+ mm_projector.bin), loadable by `from_pretrained`.  One rank writes
+        (`writer_rank`, a global rank; without torch.distributed the caller is rank 0); an expert-parallel model is saved
+        collectively with its experts gathered under global indices (`checkpoint.save_checkpoint`)."""
+        from ...checkpoint import _dist_rank_world, save_checkpoint
+        files = save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes, writer_rank=writer_rank)
+        if _dist_rank_world()[0] == writer_rank:
+            self.save_config(save_directory)
+        return files
 
     def save_mm_adapter(self, output_dir, keys_to_match=("mm_projector",)):
         """Adapter-only save of the reference's trainers (train/align_trainer.py:616-636 `_save_checkpoint` with

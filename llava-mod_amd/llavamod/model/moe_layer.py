@@ -192,8 +192,10 @@ class MoE(nn.Module):
         if El == 1:
             # ONE local expert (config 5: 8 experts on 8 ranks): the packed live rows ARE its input — no capacity slabs on the
             # receiving side, no row masks, no zero-filled dead rows: the dense fused-SwiGLU block on [Lr, H] (plain GEMM launches,
-            # K = Lr weight gradients).  A rank that received nothing skips the block (its expert's gradient span stays zero).
-            y_p = ops.MLPBlock.apply(recv_p, spec, *expert_params) if recv_p.shape[0] > 0 else recv_p
+            # K = Lr weight gradients).  A rank that received nothing launches nothing, but keeps the block's place in the backward
+            # (`ops.EmptyExpertPass`: the same wgrad-ready hooks in the same order, so the expert-data-parallel collectives are
+            # issued identically on every rank of the group; its expert's gradient span stays zero).
+            y_p = (ops.MLPBlock if recv_p.shape[0] > 0 else ops.EmptyExpertPass).apply(recv_p, spec, *expert_params)
         else:
             recv = ops.RowGather.apply(recv_p, pl.recv_slab, pl.recv_inv)                    # slabs [ep*El*C, H]
             y = ops.ExpertFFN.apply(recv.view(ep, El, C, H), spec, rr.contiguous(), *expert_params)

@@ -147,21 +147,25 @@ def _need(ctx):
 _ONES = {}
 
 
+def _ones_buf(n, device):
+    """ONE flat buffer of ones per device, grown to the largest token count seen (packed / varlen batches change the row count
+    nearly every step: a tensor per distinct count would grow device memory without bound over a long run)."""
+    key = str(device)
+    buf = _ONES.get(key)
+    need = 8 * n
+    if buf is None or buf.numel() < need:
+        buf = _ONES[key] = torch.ones(max(need, 8 * 4096), device=device, dtype=BF16)
+    return buf
+
+
 def _ones(n, device):
-    key = (n, str(device))
-    if key not in _ONES:
-        _ONES[key] = torch.ones((8, n), device=device, dtype=BF16)
-    return _ONES[key]
-
-
-_ONES_COL = {}
+    """[8, n] bf16 ones (the bias-gradient GEMM's second operand on transposed copies)."""
+    return _ones_buf(n, device)[:8 * n].view(8, n)
 
 
 def _ones_col(n, device):
-    key = (n, device.index)
-    if key not in _ONES_COL:
-        _ONES_COL[key] = torch.ones((n, 8), device=device, dtype=BF16)
-    return _ONES_COL[key]
+    """[n, 8] bf16 ones (the same operand on the tensors as autograd holds them)."""
+    return _ones_buf(n, device)[:8 * n].view(n, 8)
 
 
 def linear_fwd(x, fw, act=0, out=None):
@@ -388,6 +392,35 @@ class MLPBlock(torch.autograd.Function):
         if sp.gu.requires_grad:
             linear_wgrad(dgu, x, sp.gu)
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class EmptyExpertPass(torch.autograd.Function):
+    """The local expert of a rank that received NO rows in an expert-parallel exchange (`MoE._forward_expert_parallel`, one
+    local expert): nothing to compute, but the block's place in the backward must stay — `MLPBlock.backward` reports
+    `down.grad_done()` then `gu.grad_done()`, which is where `engine.DataParallel._on_ready` issues the spans' asynchronous
+    reduce-scatter / all-reduce over the expert-data-parallel group.  Skipping the block on the starved rank would defer its
+    spans to `finish()` while its peers send them mid-backward: the collectives of one communicator would be issued in a
+    different order on different ranks (a hang, or sums of the wrong spans).  This pass fires the same two hooks at the same
+    point; the spans keep their zeros."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        ctx.spec = spec
+        ctx.noted = []
+        if _need(ctx):
+            for fw in (spec.gu, spec.down):
+                if fw.requires_grad:
+                    fw.note_use()
+                    ctx.noted.append(fw)
+        return x.new_empty((0, spec.down.w.shape[-2]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp = ctx.spec
+        for fw in (sp.down, sp.gu):              # MLPBlock.backward's order
+            if any(fw is f for f in ctx.noted):
+                fw.grad_done()
+        return (dout.new_empty((0, sp.gu.w.shape[-1])), None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
 class MLPBlockRes(torch.autograd.Function):

@@ -169,22 +169,33 @@ class AlignTrainer:
         is saved — `config.json` (the reference calls `config.save_pretrained`) + `mm_projector.bin` holding the `mm_projector`
         parameters under their full names — and only by the rank whose `args.local_rank` is 0 or -1, like the reference (every
         rank holds the same replicated adapter; concurrent writers of one file would race).  Otherwise the full HF-layout
-        checkpoint, rank 0 only."""
+        checkpoint, written by ONE rank of the whole job — HF's `args.should_save` when the args carry it, else the GLOBAL
+        rank 0 (a `local_rank` gate would let every node's first rank write the same shard and index files).  With expert
+        parallelism (`ep_size` > 1, config 5) a rank holds only its local experts: the save is then a collective over the
+        writer's expert-parallel group — EVERY rank calls this method, the group gathers the experts, and the writer saves them
+        under global indices (`checkpoint.full_state_dict`)."""
         import os
+        from ..checkpoint import _dist_rank_world, expert_parallel_layout
         if output_dir is None:
             step = getattr(getattr(self, "state", None), "global_step", 0)
             output_dir = os.path.join(getattr(self.args, "output_dir", "."), f"checkpoint-{step}")
-        local_rank = getattr(self.args, "local_rank", -1)
-        if local_rank not in (0, -1, None):
-            return None
         if getattr(self.args, "tune_mm_mlp_adapter", False):
+            local_rank = getattr(self.args, "local_rank", -1)
+            if local_rank not in (0, -1, None):
+                return None
             keys = ["mm_projector", "vision_resampler"]
             if getattr(self.args, "use_im_start_end", False):
                 keys.extend(["embed_tokens", "embed_in"])
             os.makedirs(output_dir, exist_ok=True)
             model.save_config(output_dir)
             return model.save_mm_adapter(output_dir, keys_to_match=tuple(keys))
-        return model.save_pretrained(output_dir)
+        rank, _ = _dist_rank_world()
+        should_save = bool(getattr(self.args, "should_save", rank == 0))
+        if expert_parallel_layout(model):
+            return model.save_pretrained(output_dir) or None          # collective: the writer is global rank 0
+        if not should_save:
+            return None
+        return model.save_pretrained(output_dir, writer_rank=rank)
 
     # ---- materialising API of the reference (slow path, kept for drop-in parity) ------------------
     def get_p(self, model, inputs):

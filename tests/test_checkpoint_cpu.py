@@ -212,3 +212,70 @@ def test_named_tower_never_random_initialises(tmp_path):
     ref = LlavaQwen2ForCausalLM.from_pretrained(REF_CKPT, device="cpu")
     for (ka, va), (kb, vb) in zip(m.state_dict().items(), ref.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
+
+
+def _ep_save_worker(rank, world, port, out_dir, q):
+    """2 ranks = one expert-parallel group of size 2 over a 4-expert layer: each rank holds 2 LOCAL experts."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from llavamod.checkpoint import load_checkpoint, read_state
+    from llavamod.engine import init_distributed
+    from llavamod.train.align_trainer import AlignTrainer
+    init_distributed()
+    model, dc = _tiny(True, 1)
+    margs = U.moe_args(dc)
+    margs.ep_size = 2
+    model.initialize_moe_modules(margs)
+    ex = model.get_model().layers[0].mlp.deepspeed_moe.experts.deepspeed_experts
+    assert len(ex) == 2
+    with torch.no_grad():                               # local expert i of rank r is GLOBAL expert 2 r + i: tag it
+        for i, e in enumerate(ex):
+            for p in e.parameters():
+                p.fill_(float(2 * rank + i + 1))
+    tr = AlignTrainer(model, None, args=type("A", (), dict(output_dir=out_dir, local_rank=rank))())
+    files = tr._save_checkpoint(model, None, output_dir=os.path.join(out_dir, "ep"))     # collective: every rank calls it
+    dist.barrier()
+    assert bool(files) == (rank == 0)
+    sd = read_state(os.path.join(out_dir, "ep"))
+    for g in range(4):                                  # ONE file set holding all four experts under global indices
+        t = sd[f"model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.{g}.up_proj.weight"]
+        assert bool((t.float() == g + 1).all()), g
+    assert os.path.exists(os.path.join(out_dir, "ep", "config.json"))
+    assert not [f for f in os.listdir(os.path.join(out_dir, "ep")) if ".tmp" in f]
+    # the expert-parallel model reads its own local experts back from the global names
+    with torch.no_grad():
+        for e in ex:
+            for p in e.parameters():
+                p.zero_()
+    assert load_checkpoint(model, os.path.join(out_dir, "ep")) == ([], [])
+    for i, e in enumerate(ex):
+        assert all(bool((p.float() == 2 * rank + i + 1).all()) for p in e.parameters())
+    # and an ep_size = 1 model (what the FineTune / Eval classes build) loads the same files
+    if rank == 0:
+        full, dc1 = _tiny(True, 3)
+        full.initialize_moe_modules(U.moe_args(dc1))
+        assert load_checkpoint(full, os.path.join(out_dir, "ep")) == ([], [])
+        ex1 = full.get_model().layers[0].mlp.deepspeed_moe.experts.deepspeed_experts
+        assert [float(e.down_proj.weight.float().mean()) for e in ex1] == [1.0, 2.0, 3.0, 4.0]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_expert_parallel_checkpoint_gathers_experts_under_global_names(tmp_path):
+    """with ep_size > 1 a single writer used to save only ITS local experts (under local indices) and silently drop
+    the others.  The save is now a collective over the writer's expert-parallel group; the files hold every expert under its
+    global index, written through temporary names."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ep_save_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]

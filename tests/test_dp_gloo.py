@@ -481,3 +481,81 @@ def test_four_rank_gloo_expert_data_parallel_groups():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = sorted(q.get(timeout=5) for _ in range(4))
     assert got == [(r, "ok") for r in range(4)]
+
+
+def _starved_expert_worker(rank, world, port, q):
+    """World 4 = expert-parallel size 2 x expert-data-parallel size 2, ONE local expert per rank.  Rank 2 receives
+    no rows for its expert in this step, its expert-data-parallel peer (rank 0) does.  The peer's `MLPBlock.backward` reports
+    down-then-gate/up as their weight gradients are enqueued, and `DataParallel._on_ready` issues the two spans' collectives
+    over the pair's communicator right there; the starved rank runs `ops.EmptyExpertPass`, which must fire the same hooks in the
+    same order — otherwise its spans would only go out in `finish()`, in buffer order (gate/up first), against the peer's
+    down-first: two different sequences of differently sized collectives on one communicator."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")
+    from llavamod import ops
+    from llavamod.engine import DataParallel, GradBuffer, init_distributed
+    from llavamod.model.language_model.qwen2_hip import Qwen2Config, Qwen2DecoderLayer
+    from llavamod.model.moe_layer import MoE
+    from types import SimpleNamespace
+    init_distributed()
+    ep = 2
+    cfg = Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1)
+    layer = Qwen2DecoderLayer(cfg, "cpu")
+    layer.mlp = MoE(64, layer.mlp, num_experts=2, ep_size=ep, k=1, capacity_factor=1.0, min_capacity=0)
+    assert layer.mlp.num_local_experts == 1
+    for n, p in layer.named_parameters():
+        p.requires_grad = "mlp" in n
+    gb = GradBuffer(layer)
+    dp = DataParallel(bucket_bytes=1 << 20).attach(gb, ep_size=ep)
+    gu, down = layer.mlp._gu, layer.mlp._down
+    gu.ensure(); down.ensure()
+    sent = []
+    real_send = dp._send
+    dp._send = lambda obj, kind: (sent.append("gu" if obj is gu else "down" if obj is down else "other"), real_send(obj, kind))[1]
+    spec = SimpleNamespace(gu=gu, down=down)
+
+    class FedBlock(torch.autograd.Function):          # MLPBlock's contract with the engine, without its kernels
+        @staticmethod
+        def forward(ctx, x, sp, *params):
+            ctx.sp = sp
+            sp.gu.note_use(); sp.down.note_use()
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, dout):
+            sp = ctx.sp
+            sp.down.grad_buffer().add_(1.0 + rank); sp.down.grad_done()
+            sp.gu.grad_buffer().add_(10.0 + rank); sp.gu.grad_done()
+            return (dout * 2.0, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+    params = [p for p in layer.mlp.deepspeed_moe.experts.parameters() if p.requires_grad]
+    starved = rank == 2
+    gb.zero()
+    x = torch.zeros((0 if starved else 3, 64), dtype=torch.bfloat16, requires_grad=True)
+    y = (ops.EmptyExpertPass if starved else FedBlock).apply(x, spec, *params)
+    assert y.shape == (x.shape[0], 64)
+    y.float().sum().backward()
+    assert sent == ["down", "gu"], (rank, sent)                # both spans went out DURING backward, in MLPBlock's order
+    assert x.grad.shape == x.shape
+    dp.finish()
+    peers = [r for r in range(world) if r % ep == rank % ep]
+    fed = [r for r in peers if r != 2]
+    assert bool((down.grad_buffer() == sum(1.0 + r for r in fed)).all()), rank
+    assert bool((gu.grad_buffer() == sum(10.0 + r for r in fed)).all()), rank
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_four_rank_gloo_starved_expert_keeps_collective_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_starved_expert_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(4))
+    assert got == [(r, "ok") for r in range(4)]

@@ -27,12 +27,24 @@ def rnd(*shape, scale=1.0, seed=None):
     return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
 
 
-def close(out, ref, name, rtol=2 ** -7, afrac=2 ** -8):
+def close(out, ref, name, rtol=2 ** -7, afrac=2 ** -8, scale=None):
+    """|out - ref| <= rtol |ref| + afrac * S.  S is the magnitude the absolute term is taken from:
+      * default: the maximum of |ref| over the element's own ROW (last dimension) — not over the whole tensor, which let an
+        error confined to a row of small-magnitude outputs (a wrong tail row of a grouped launch, say) hide under 0.4 % of some
+        other row's maximum;
+      * `scale` (a tensor like ref): the element's own natural scale, e.g. sum_k |a_mk| |b_nk| for a dot product — the bound
+        the GEMM family's scaled-operand test uses (`test_gemm_scaled_rows_and_columns_elementwise_bound`)."""
     out, ref = out.float(), ref.float()
     assert out.shape == ref.shape, f"{name}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(out).all(), f"{name}: non-finite output"
     err = (out - ref).abs()
-    bound = afrac * ref.abs().max().clamp_min(1e-30) + rtol * ref.abs()
+    if scale is not None:
+        S = scale.float()
+    elif ref.dim() >= 2:
+        S = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    else:
+        S = ref.abs().max().clamp_min(1e-30)
+    bound = afrac * S + rtol * ref.abs()
     bad = err > bound
     if bad.any():
         i = torch.argmax(err - bound)
@@ -62,6 +74,21 @@ def test_gemm_random_shapes(M, N, K_):
     a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2)
     c = K_gemm(a, b)
     close(c, a.float() @ b.float().t(), f"gemm {M}x{N}x{K_}")
+
+
+@pytest.mark.parametrize("M,N,K_", [(4000, 2568, 200), (300, 136, 2048), (8192, 4096, 1024)])
+def test_gemm_scaled_rows_and_columns_elementwise_bound(M, N, K_):
+    """Rows of A and rows of B scaled by powers of two from 2^-8 to 2^8: the outputs span 2^-16 ... 2^16, so a tolerance tied to
+    the tensor's (or even a row's) maximum would accept garbage in the small-magnitude rows and columns — ragged tails included.
+    Each element is held to ITS OWN scale: 2^-7 |ref| (two bf16 roundings) + 2^-12 sum_k |a_mk| |b_nk| (accumulation order).
+    Covers the 128-tile kernel, the 8-wave and the 4-wave asm kernels (persistent from 4 rounds of the CUs)."""
+    a, b = rnd(M, K_, seed=90), rnd(N, K_, seed=91)
+    sa = torch.pow(2.0, torch.arange(M, device=DEV) % 17 - 8.0).to(BF)[:, None]
+    sb = torch.pow(2.0, (torch.arange(N, device=DEV) * 5) % 17 - 8.0).to(BF)[:, None]
+    a, b = (a * sa).contiguous(), (b * sb).contiguous()        # exact: powers of two
+    ref = a.float() @ b.float().t()
+    mag = a.float().abs() @ b.float().abs().t()
+    close(K_gemm(a, b), ref, f"scaled gemm {M}x{N}x{K_}", rtol=2 ** -7, afrac=2 ** -12, scale=mag)
 
 
 def test_gemm_big_tile_path_all_epilogues():
