@@ -17,7 +17,7 @@
  *   - the communicator handles behind lmod_comm_* (owned by the caller through their opaque pointers);
  *   - measurement switches from the environment, documented beside their readers in csrc/ — read once at first use:
  *     LMOD_GEMM_WAVES, LMOD_ATTN_FWD, LMOD_ATTN_BWD, LMOD_WGRAD_SPLIT; read at every launch (so that one test process can
- *     run both arms of an A/B): LMOD_GEMM_PERSIST, LMOD_GEMM_PERSIST_ROUNDS, LMOD_GEMM_KV4, LMOD_GEMM_TN4, LMOD_GEMM_TILE.
+ *     run both arms of an A/B): LMOD_GEMM_PERSIST, LMOD_GEMM_PERSIST_GROUPED, LMOD_GEMM_PERSIST_ROUNDS, LMOD_GEMM_KV4, LMOD_GEMM_SB4, LMOD_GEMM_TN4, LMOD_GEMM_TILE.
  *     Unset, they select the shipped routing; none changes results (each pair of arms is bit-identical, tests/test_kernels_gpu.py).
  */
 #ifndef LMOD_HIP_H

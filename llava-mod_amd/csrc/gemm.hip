@@ -130,6 +130,30 @@ __device__ __forceinline__ bool grouped_tile(const GemmP& p, int& bz, int& tm, i
   return true;
 }
 
+// The same mapping for a PERSISTENT workgroup (gemm4_kernel<MODE, true, true>): the per-batch live row-tile counts were read once
+// at kernel entry — before any store of the launch, so they are scalar loads and every derived value stays in SGPRs — and the
+// tile id is the walk's own (`bid`), not blockIdx.x.  `nlive` = total * tiles_n.
+template <int GROUP_M>
+__device__ __forceinline__ bool grouped_tile_pre(const GemmP& p, const int (&rows)[GEMM_MAX_GROUPS], const int total, const int nlive,
+                                                 const int bid, int& bz, int& tm, int& tn) {
+  if (bid >= nlive) return false;
+  const int id = xcd_remap(bid, nlive);
+  const int grp = id / (GROUP_M * p.tiles_n);
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(total - first_m, GROUP_M);
+  const int rr = id - grp * GROUP_M * p.tiles_n;
+  int vr = first_m + rr % gsz;
+  tn = rr / gsz;
+  bz = 0;
+#pragma unroll
+  for (int e = 0; e < GEMM_MAX_GROUPS; ++e) {
+    const int live = (rows[e] + 255) >> 8;          // (only the live ROWS are carried: 16 scalars instead of 32)
+    if (e < p.batch && bz == e && vr >= live) { vr -= live; bz = e + 1; }
+  }
+  tm = vr;
+  return true;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB + B 16 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1357,8 +1381,12 @@ struct G4Tile {      // one output tile: coordinates, operand windows, this lane
 // next tile's first fragments in registers and its second K tile in flight, and its C stores drain under the next tile's first
 // MFMAs — no workgroup turn-around, no prologue latency, no store drain on the critical path.  Plain launches with K % 64 == 0,
 // K >= 256 (the launcher decides); results are those of the one-tile-per-workgroup form, bit for bit.
-template <int MODE, bool PERSIST = false>
+// PG (round 5): the persistent form for GROUPED launches (MoE capacity slabs, `m_valid` live rows per batch, batch <=
+// GEMM_MAX_GROUPS): the walk runs over the LIVE tiles only (their count is computed in the kernel from m_valid; dead tiles are
+// never visited, so there is nothing to skip), with the same continuous operand stream across tiles.
+template <int MODE, bool PERSIST = false, bool PG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4_kernel(GemmP p) {
+  static_assert(!PG || PERSIST, "PG is a persistent form");
   constexpr int TN = (MODE == 1) ? 128 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB
   // (not const: the persistent form re-launders them once per tile, see G4_LAUNDER)
@@ -1367,11 +1395,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int wr = wave >> 1, wc = wave & 1;
 
   const int tpb = p.tiles_m * p.tiles_n;
+  // PG: live rows and live row tiles of every batch, read ONCE here (scalar loads: nothing of this launch has been stored yet)
+  int pg_rows[GEMM_MAX_GROUPS], pg_total = 0;
+  if constexpr (PG) {
+#pragma unroll
+    for (int e = 0; e < GEMM_MAX_GROUPS; ++e) {
+      pg_rows[e] = 0;
+      if (e < p.batch) {
+        pg_rows[e] = __builtin_amdgcn_readfirstlane(min(p.m_valid[e], p.M));
+        pg_total += (pg_rows[e] + 255) >> 8;
+      }
+    }
+  }
+  const int pg_nlive = pg_total * p.tiles_n;
   // staging: piece j of wave w fills LDS rows (j*4 + w)*8 + (lane>>3), physical chunk lane&7 (logical chunk ^ row&7)
   int cchunk = G4_PAD ? (lane & 7) : ((lane & 7) ^ (lane >> 3));
   auto setup = [&](const int bid, const int nwg, G4Tile& T) -> bool {
-    // persistent launches carry no m_valid / k_valid (launcher): without the `PERSIST ? nullptr` below their loads — re-issued
-    // after the previous tile's stores, so not scalarisable — drag the whole tile arithmetic into VGPRs
+    // persistent launches carry no k_valid, and no m_valid unless PG (launcher): without the `PERSIST ? nullptr` below their loads —
+    // re-issued after the previous tile's stores, so not scalarisable — drag the whole tile arithmetic into VGPRs (PG reads its
+    // counts from the pg_* registers filled at kernel entry instead)
     const int* const mvp = PERSIST ? nullptr : p.m_valid;
     const int* const kvp = PERSIST ? nullptr : p.k_valid;
     int id = xcd_remap(bid, nwg);
@@ -1414,7 +1456,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tm = rem - bz * p.tiles_m;
       }
     }
-    const int Mv = mvp ? min(mvp[bz], p.M) : p.M;
+    int Mv = mvp ? min(mvp[bz], p.M) : p.M;
+    if constexpr (PG) {
+      if (!grouped_tile_pre<G256_GROUP_M>(p, pg_rows, pg_total, pg_nlive, bid, bz, tm, tn)) return false;
+      Mv = 0;
+#pragma unroll
+      for (int e = 0; e < GEMM_MAX_GROUPS; ++e) Mv = (e == bz) ? pg_rows[e] : Mv;
+      id = bz * tpb + tm * p.tiles_n + tn;
+    }
     int Kv = kvp ? min(kvp[bz], p.K) : p.K;
     const int row0 = tm * 256, col0 = tn * TN;
     if (row0 >= Mv) return false;
@@ -1475,8 +1524,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   G4Tile T;
   int pbid = blockIdx.x;
-  const int ptotal = PERSIST ? p.ptotal : (int)gridDim.x;
-  if (!setup(pbid, ptotal, T)) return;                     // (persistent launches carry no m_valid: every tile id is live)
+  const int ptotal = PG ? pg_nlive : (PERSIST ? p.ptotal : (int)gridDim.x);
+  if (!setup(pbid, ptotal, T)) return;                     // (persistent walks see live tiles only; PG: a workgroup past the live count)
   stage_tiles01(T);
   bf16x8 fa[2][8], fb[2][8];
   // PERSIST: what the K loop carries from one tile to the next — the LDS stage parity (fragment addresses, LDS-DMA base) and the
@@ -2602,9 +2651,28 @@ static bool gemm_persist(const GemmP& p, long long nwg) {
   return on && G4_ASM && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus() && nwg >= (long long)min_rounds * gemm_cus() &&
          (p.K & 63) == 0 && p.K >= 256;
 }
+// The persistent form of a GROUPED launch (round 5; MoE capacity slabs: m_valid live rows per batch): `nwg` counts the slabs' tiles,
+// dead ones included (capacity factor 1.5: about a third) — the live count is only known on the device, where the kernel computes
+// it.  LMOD_GEMM_PERSIST_GROUPED=0 keeps one tile per workgroup (A/B arm; read per launch).
+static bool gemm_persist_grouped(const GemmP& p, long long nwg) {
+  const char* e = getenv("LMOD_GEMM_PERSIST");
+  const char* g = getenv("LMOD_GEMM_PERSIST_GROUPED");
+  const int on = (e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT) && (g ? atoi(g) != 0 : 1);
+  const char* r = getenv("LMOD_GEMM_PERSIST_ROUNDS");
+  const int min_rounds = r ? atoi(r) : 4;
+  return on && G4_ASM && p.m_valid && !p.k_valid && p.splitk <= 1 && p.batch >= 1 && p.batch <= GEMM_MAX_GROUPS &&
+         nwg >= (long long)min_rounds * gemm_cus() && (p.K & 63) == 0 && p.K >= 256;
+}
 template <int MODE>
 static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
-  static bool a = false, ap = false;
+  static bool a = false, ap = false, apg = false;
+  if constexpr (MODE == 1 || MODE == 7) {
+    if (gemm_persist_grouped(p0, nwg)) {
+      allow_lds(gemm4_kernel<MODE, true, true>, 2 * G4_STAGE, apg);
+      hipLaunchKernelGGL((gemm4_kernel<MODE, true, true>), dim3((unsigned)gemm_cus()), dim3(256), 2 * G4_STAGE, stream, p0);
+      return;
+    }
+  }
   if (gemm_persist(p0, nwg)) {
     GemmP p = p0;
     p.ptotal = (int)nwg;
@@ -2615,6 +2683,7 @@ static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
     hipLaunchKernelGGL((gemm4_kernel<MODE, false>), dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p0);
   }
 }
+static bool gemm_sb4() { const char* e = getenv("LMOD_GEMM_SB4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 keeps the dense fused SwiGLU backward on the 8-wave kernel)
 static bool gemm_kv4() { const char* e = getenv("LMOD_GEMM_KV4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 keeps k_valid batches on the 8-wave kernel)
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
@@ -2629,9 +2698,12 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   } else if (w == 4) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
-  } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3) {     // (in-step: 1177 us per launch against 1124 us for
-    (void)a44;                                                                          //  the 8-wave kernel's two-batch epilogue: not routed)
-    launch_4<4>(p, nwg, stream);                                                        // persistent when the launch qualifies (dense layers)
+  } else if (MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3 && (w == 44 || (w == 0 && gemm_sb4() && gemm_persist(p, nwg)))) {
+    // fused SwiGLU backward: launches that take the PERSISTENT 4-wave form (dense layers: no m_valid, >= 4 rounds of the CUs) run
+    // 2.8 - 3.8 % faster there, bit-identical (round 5 routing; tools/probe/swiglu_bwd_variants.py; LMOD_GEMM_SB4=0 is the A/B arm);
+    // grouped (MoE) launches keep the 8-wave instantiation with its two-batch epilogue (one tile per workgroup: 1124 vs 1177 us)
+    (void)a44;
+    launch_4<4>(p, nwg, stream);
   } else if ((w == 0 || w == 44) && MODE == 0 && p.splitk <= 1 && !p.k_valid && !p.out_f32 && !p.accumulate && p.act != 3) {
     launch_4<7>(p, nwg, stream);
   } else if (w == 44 && MODE == 0 && p.splitk <= 1 && !p.k_valid && p.out_f32 && p.accumulate && !p.act && !p.bias && p.vec_ok) {   // (not routed: the 8-wave MODE 6 has the two-batch read-modify-write)

@@ -296,6 +296,42 @@ def test_gemm_fused_swiglu_grouped():
         assert n8 == C or (act[e, n8:] == 7.0).all(), "rows past the zeroed chunk must not be written"
 
 
+@pytest.mark.parametrize("K_", [256, 1024])
+@pytest.mark.parametrize("rows", [[2304, 0, 1100, 3000, 257, 2048], [3000] * 6, [0, 0, 5, 0, 0, 2999], [256] * 16])
+def test_gemm_grouped_persistent_walk_is_bit_identical(K_, rows, monkeypatch):
+    """Round 5: grouped launches (MoE capacity slabs, live rows per expert in `m_valid`) on the PERSISTENT four-wave kernel — one
+    workgroup per CU walks the LIVE tiles only (live count computed in the kernel), operand stream continuous across tiles and
+    across experts.  Plain grouped GEMM (the experts' down projection / dgrad) and the grouped fused SwiGLU forward, against the
+    one-tile-per-workgroup form of the same launches: bit-identical outputs, dead rows untouched, rows up to the next multiple of 8
+    zeroed by the SwiGLU form.  Cases: ragged counts with an empty expert and a 1-row tile tail; all slabs full; almost everything
+    dead (fewer live tiles than CUs: most workgroups exit at once); 16 experts of exactly one row tile."""
+    E, C = len(rows), 3000 if max(rows) > 256 else 256
+    H, I = K_, 1280                                               # 12 x 5 = 60 column tiles... per row tile: N 1280 -> 5 tiles of 256
+    x, w = rnd(E, C, H, seed=40 + K_), rnd(E, I, H, seed=41 + K_)
+    wgu = rnd(E, 2 * I, H, seed=42 + K_)
+    mv = torch.tensor(rows, device=DEV, dtype=torch.int32)
+    monkeypatch.setenv("LMOD_GEMM_PERSIST", "1")
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_ROUNDS", "0")           # every grouped launch takes the persistent form
+
+    def run():
+        out = torch.full((E, C, I), 7.0, device=DEV, dtype=BF)
+        K.gemm_nt(x, w, out=out, m_valid=mv)
+        act = torch.full((E, C, I), 7.0, device=DEV, dtype=BF)
+        gu = torch.full((E, C, 2 * I), 7.0, device=DEV, dtype=BF)
+        K.gemm_swiglu(x, wgu, act=act, gu=gu, m_valid=mv)
+        return out, act, gu
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_GROUPED", "1")
+    o1, a1, g1 = run()
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_GROUPED", "0")
+    o0, a0, g0 = run()
+    assert torch.equal(o1, o0) and torch.equal(a1, a0) and torch.equal(g1, g0)
+    for e in range(E):
+        n = rows[e]
+        if n:
+            close(o1[e, :n], x[e, :n].float() @ w[e].float().t(), f"grouped persistent expert {e}")
+        assert n == C or (o1[e, n:] == 7.0).all(), "dead rows must not be written"
+
+
 def test_gemm_fused_swiglu_backward():
     # down-projection dgrad with swiglu_bwd in the epilogue == GEMM + swiglu_bwd kernel, bit for bit; grouped + dead rows
     M, H, I = 300, 136, 272
