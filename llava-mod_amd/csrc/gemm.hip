@@ -2653,11 +2653,16 @@ static bool gemm_persist(const GemmP& p, long long nwg) {
 }
 // The persistent form of a GROUPED launch (round 5; MoE capacity slabs: m_valid live rows per batch): `nwg` counts the slabs' tiles,
 // dead ones included (capacity factor 1.5: about a third) — the live count is only known on the device, where the kernel computes
-// it.  LMOD_GEMM_PERSIST_GROUPED=0 keeps one tile per workgroup (A/B arm; read per launch).
-static bool gemm_persist_grouped(const GemmP& p, long long nwg) {
+// it.  Measured (profiles/r05_grouped_persistent.jsonl, config-2 MoE shapes, same box, bit-identical): the grouped fused SwiGLU
+// forward +3.1 ... 4.4 % (1229 -> 1268 TF; 128-column tiles, 32 K tiles per tile: the largest epilogue share), the plain grouped
+// launches level (down projection +4.5 / -1.0 %, gate/up dgrad -0.6 %: 256-column tiles, K 5504 / 11008).  So the default (1) routes
+// the fused SwiGLU forward only; LMOD_GEMM_PERSIST_GROUPED=2 adds the plain grouped launches, 0 keeps one tile per workgroup
+// (A/B arms; read per launch).
+static bool gemm_persist_grouped(const GemmP& p, long long nwg, const int mode) {
   const char* e = getenv("LMOD_GEMM_PERSIST");
   const char* g = getenv("LMOD_GEMM_PERSIST_GROUPED");
-  const int on = (e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT) && (g ? atoi(g) != 0 : 1);
+  const int lvl = g ? atoi(g) : 1;
+  const int on = (e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT) && (mode == 1 ? lvl >= 1 : lvl >= 2);
   const char* r = getenv("LMOD_GEMM_PERSIST_ROUNDS");
   const int min_rounds = r ? atoi(r) : 4;
   return on && G4_ASM && p.m_valid && !p.k_valid && p.splitk <= 1 && p.batch >= 1 && p.batch <= GEMM_MAX_GROUPS &&
@@ -2667,7 +2672,7 @@ template <int MODE>
 static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
   static bool a = false, ap = false, apg = false;
   if constexpr (MODE == 1 || MODE == 7) {
-    if (gemm_persist_grouped(p0, nwg)) {
+    if (gemm_persist_grouped(p0, nwg, MODE)) {
       allow_lds(gemm4_kernel<MODE, true, true>, 2 * G4_STAGE, apg);
       hipLaunchKernelGGL((gemm4_kernel<MODE, true, true>), dim3((unsigned)gemm_cus()), dim3(256), 2 * G4_STAGE, stream, p0);
       return;

@@ -33,14 +33,17 @@ def test_distill_all_tokens_ragged_step_vs_oracle():
     batch = P._mid_batch(41, 3, 48, sc.vocab_size, vc.image_size, True)
     assert not bool(batch["attention_mask"].all())
     r = P._mimic_parity_case(vc, sc, tc, 5, batch, [None, None], "distill_all_tokens (ragged)", distill_all=True)
-    # the knob is live: the same models and batch under the label mask give another align loss
+    # the knob is live in the product's loss plan: every row of the spliced [B, S'] grid is a KD row, pads included
     from llavamod.train.align_trainer import AlignTrainer
     hb = dict(batch, images=batch["images"].to(P.DEV).to(torch.bfloat16))
-    tr = AlignTrainer(r.student, r.teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=False, loss_type="kd_lm",
-                                                                    moe_loss_enable=True))(), align_vocab=sc.vocab_size)
-    with torch.no_grad():
-        _, outs = tr.compute_loss(r.student, hb, return_outputs=True)
-    assert abs(float(outs["loss/align"]) - float(r.logs_o["loss/align"])) > 1e-3 * abs(float(r.logs_o["loss/align"]))
+    n_kd = {}
+    for flag in (True, False):
+        tr = AlignTrainer(r.student, r.teacher, args=type("A", (), dict(moe_enable=True, distill_all_tokens=flag, loss_type="kd_lm",
+                                                                        moe_loss_enable=True))(), align_vocab=sc.vocab_size)
+        n_kd[flag] = float(tr._teacher_pass(tr._batch_of(hb)).plan.kd_w.sum())
+    B, Sp = batch["input_ids"].shape[0], batch["input_ids"].shape[1] - 1 + vc.num_patches
+    n_pad = int((~batch["attention_mask"]).sum())
+    assert n_pad > 0 and n_kd[True] == B * Sp and n_kd[False] < n_kd[True] - n_pad
 
 
 @pytest.mark.parametrize("mode,expect", [("first_half", [0, 1]), ("second_half", [2, 3]), ("dense", [0, 1, 2, 3])])

@@ -34,7 +34,7 @@ def ab(name, env, fn, flops, check=None):
     out = {}
     res = {}
     for arm in ("0", "1", "0", "1"):
-        os.environ[env] = arm
+        os.environ[env] = ("2" if env == "LMOD_GEMM_PERSIST_GROUPED" else "1") if arm == "1" else "0"
         dt = t(fn)
         res.setdefault(arm, []).append(flops / dt / 1e12)
         if check is not None:
