@@ -301,11 +301,22 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                     rejected_input_ids=rj["input_ids"], rejected_labels=rj["labels"], rejected_attention_mask=rj["attention_mask"],
                     images=b["images"])
         hist, handles = _record_picks(o_student)
-        t0 = time.time()
-        _, logs = dpo_step(o_student, o_teacher, dict(pair, images=pair["images"].float()), beta=0.1, loss_type="kto_pair")
+        from oracle import losses as olosses
+        fpair = dict(pair, images=pair["images"].float())
+        och = dict(input_ids=fpair["chosen_input_ids"], labels=fpair["chosen_labels"], attention_mask=fpair["chosen_attention_mask"], images=fpair["images"])
+        orj = dict(input_ids=fpair["rejected_input_ids"], labels=fpair["rejected_labels"], attention_mask=fpair["rejected_attention_mask"], images=fpair["images"])
+        t0 = time.time()                 # oracle.llava.dpo_step, spelled out so that the four outputs stay in hand (per-token log-probs below)
+        o_sch, o_srj = o_student(**och), o_student(**orj)
+        with torch.no_grad():
+            o_tch, o_trj = o_teacher(**och), o_teacher(**orj)
+        loss_o, logs = olosses.preference_loss(o_sch, o_srj, o_tch, o_trj, 0.1, 0.0, "kto_pair", True)
+        loss_o.backward()
         t_cpu = time.time() - t0
         for h in handles:
             h.remove()
+        tok_ref = {"policy/chosen": _token_logps(o_sch.logits, o_sch.labels), "policy/rejected": _token_logps(o_srj.logits, o_srj.labels),
+                   "reference/chosen": _token_logps(o_tch.logits, o_tch.labels), "reference/rejected": _token_logps(o_trj.logits, o_trj.labels)}
+        del o_sch, o_srj, o_tch, o_trj, loss_o
         tf = 2.0 * mimic_tflop(t_layers=t_l, s_dense=s_l // 2, s_moe=s_l // 2, vit_layers=vit_l)
         out = {"value": round(1.0 / t_cpu if full else (tf / t_cpu) / (2 * TFLOP_PER_SAMPLE_LEDGER), 5), "unit": "pairs/s", "cores": cores, "kind": "port",
                "sample": (f"oracle fp32 torch-CPU preference step (kto_pair) on ONE chosen/rejected pair, S=2048 each, "
@@ -322,10 +333,9 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                 m.deterministic, m.gate_noise = d, n
             # FULL-DEPTH bf16 noise floor (VERDICT r04 next #1a): the oracle's bf16 twin on the same pair, once with the fp32
             # run's expert picks forced (rounding only) and once routing on its own (rounding + its own near-tie flips)
-            tw_logs, twin_note = {}, None
+            tw_logs, twin_note, tok_tw = {}, None, {}
             if twin_device != "off":
                 try:
-                    from oracle import losses as olosses
                     o_student.zero_grad(set_to_none=True)
                     tdev = torch.device(twin_device if twin_device == "cpu" else next(student.parameters()).device)
                     t0 = time.time()
@@ -336,11 +346,15 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                     rj_ = dict(input_ids=tp["rejected_input_ids"], labels=tp["rejected_labels"], attention_mask=tp["rejected_attention_mask"], images=tp["images"])
                     with torch.device(tdev), torch.no_grad():
                         t_ch, t_rj = tw_t(**ch), tw_t(**rj_)
+                        tok_tw["reference/chosen"] = {"twin": _token_logps(t_ch.logits, t_ch.labels)}
+                        tok_tw["reference/rejected"] = {"twin": _token_logps(t_rj.logits, t_rj.labels)}
                         for tag, forced in (("forced", True), ("free", False)):
                             for m, h in zip(_oracle_moes(tw_s), hist):
                                 m.forced = [(a.to(tdev), b.to(tdev)) for a, b in h] if forced else None
                             s_ch, s_rj = tw_s(**ch), tw_s(**rj_)
                             _, tw_logs[tag] = olosses.preference_loss(s_ch, s_rj, t_ch, t_rj, 0.1, 0.0, "kto_pair", True)
+                            tok_tw.setdefault("policy/chosen", {})["twin_" + tag] = _token_logps(s_ch.logits, s_ch.labels)
+                            tok_tw.setdefault("policy/rejected", {})["twin_" + tag] = _token_logps(s_rj.logits, s_rj.labels)
                             del s_ch, s_rj
                     twin_note = (f"oracle bf16 twin (bf16 weights + activations, fp32 router) of both models at FULL depth on the same pair, "
                                  f"eager torch on {tdev.type}, {time.time() - t0:.1f} s: floor_forced = |twin - fp32| / |fp32| with the fp32 run's expert picks "
@@ -359,6 +373,38 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
             out["loss_delta"] = ld
             if twin_note:
                 out["floor_note"] = twin_note
+            # The statistic that CAN be tested: per-token log p(label) of the four sequences (512 labelled tokens each) against the
+            # fp32 oracle — root-mean-square and mean of the differences for the GPU product path and for the twin.  A logged scalar
+            # above is ONE draw of a sum of 512 such differences (and the loss a sigmoid of differences of four such sums), so the
+            # ratio of two single draws says little; the per-token RMS is an average over 512 draws.
+            try:
+                dev = next(student.parameters()).device
+                dp_ = _to_dev(pair, dev)
+                seqs = {"chosen": dict(input_ids=dp_["chosen_input_ids"], labels=dp_["chosen_labels"], attention_mask=dp_["chosen_attention_mask"], images=dp_["images"]),
+                        "rejected": dict(input_ids=dp_["rejected_input_ids"], labels=dp_["rejected_labels"], attention_mask=dp_["rejected_attention_mask"], images=dp_["images"])}
+                tok = {}
+                for m in moes:
+                    m.deterministic, m.gate_noise = True, None
+                with torch.no_grad():
+                    for who, mdl in (("policy", student), ("reference", teacher)):
+                        for side, b_ in seqs.items():
+                            o_ = mdl(**b_)
+                            r_ = tok_ref[f"{who}/{side}"]
+                            e = {"gpu_bf16": _token_stats(_token_logps(o_.logits, o_.labels), r_)}
+                            for kname, tv in tok_tw.get(f"{who}/{side}", {}).items():
+                                e[kname] = _token_stats(tv, r_)
+                            tw_rms = max([v["rms"] for kk, v in e.items() if kk != "gpu_bf16"] or [0.0])
+                            e["gpu_rms_over_twin_rms"] = round(e["gpu_bf16"]["rms"] / tw_rms, 3) if tw_rms > 0 else None
+                            tok[f"{who}/{side}"] = e
+                            del o_
+                for m, (d, n) in zip(moes, old):
+                    m.deterministic, m.gate_noise = d, n
+                out["token_logp_vs_fp32"] = tok
+                out["token_logp_note"] = ("per labelled token: log p(label) of the GPU product path (full-logits forward of the same models) and of the oracle's "
+                                          "bf16 twin minus the fp32 oracle's; rms / bias over the sequence's 512 tokens, sum_dev = the deviation of the "
+                                          "sequence log-probability, rms_x_sqrt_n = what a sum of independent errors of that rms would deviate by")
+            except Exception as e:
+                out["token_logp_vs_fp32"] = {"error": repr(e)[:300]}
         return out
     hist, handles = _record_picks(o_student) if full else ([], [])
     t0 = time.time()
@@ -499,6 +545,20 @@ def _record_picks(o_student):
 def _to_dev(batch, device):
     return {k: (v.to(device=device, dtype=torch.bfloat16) if v.is_floating_point() else v.to(device)) if torch.is_tensor(v) else v
             for k, v in batch.items()}
+
+
+def _token_logps(logits, labels):
+    """Per-token log p(label) on the shifted, labelled positions of ONE sequence (dpo_trainer.py:483-495 before the sum): fp32 [n]."""
+    lb = labels[0, 1:]
+    keep = lb != -100
+    lg = logits[0, :-1][keep].float()
+    return torch.gather(lg.log_softmax(-1), 1, lb[keep].unsqueeze(1).to(lg.device)).squeeze(1).detach().cpu()
+
+
+def _token_stats(x, ref):
+    d = (x - ref).double()
+    return {"n": int(d.numel()), "rms": round(float(d.pow(2).mean().sqrt()), 6), "bias": round(float(d.mean()), 6),
+            "sum_dev": round(float(d.sum()), 4), "rms_x_sqrt_n": round(float(d.pow(2).mean().sqrt()) * d.numel() ** 0.5, 4)}
 
 
 def _floor_entry(g, c, tw_forced, tw_free):
@@ -651,6 +711,11 @@ def main():
     B = args.micro_batch
 
     def build_student(experts):
+        # the routers are created by `MoE(...)` like DeepSpeed's TopKGate: nn.Linear's default init from torch's GLOBAL generator.
+        # Seed it — the same on every rank (data-parallel replicas must start equal; a checkpoint load / DeepSpeed's rank-0
+        # broadcast does that for the reference) and the same in every process (the synthetic benchmark's routing, and with it
+        # the live rows of every grouped launch, must not depend on what the process drew before)
+        torch.manual_seed(20240 + experts)
         st = LLaVAMoDQwen2ForCausalLM(student_cfg(experts), device=dev)
         st.initialize_moe_modules(moe_model_args(experts, ep_size=args.ep))
         for p in st.get_model().mm_projector.parameters():
