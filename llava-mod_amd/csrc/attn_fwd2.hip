@@ -56,6 +56,11 @@ __device__ unsigned long long f2_trace_buf[8 * 128];
 #endif                              //    FMAs / adds).  Measured round 4: 752 -> 505 TF (B16 S2048 causal) — the even-aligned register pairs cost
 #if 0                               //    hipcc 34-39 spilled VGPRs and compiler moves through a[0:63] (the ISA audit in tests/test_abi.py fails)
 #endif
+#ifndef F2_DMA
+#define F2_DMA 1                    // round 5: K / V tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction): no
+#endif                              //   staging registers, no ds_write issue slots, no in-loop wait on a register load (0: the round-2 path —
+                                    //   global -> 16 VGPRs -> ds_write_b128 one iteration later; the timing ablation "no staging" read +18 %
+                                    //   at B16 S2048 causal, profiles/r05_attn_ablation.md)
 #ifndef F2_TOUCH
 #define F2_TOUCH 0                  // > 0: L2 touch of the K / V tiles this many iterations ahead of their register loads
 #endif
@@ -325,6 +330,29 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // sits in the vector offset: a raw buffer's range check does not see the scalar offset)
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long long)(S - 1) * p.ldk + HD) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long long)(S - 1) * p.ldv + HD) * 2), 0x00020000);
+#if F2_DMA
+  // LDS-DMA: one wave-instruction fills 1 KiB = 4 consecutive key rows of a tile image; lane l writes bytes [16 l, 16 l + 16) of the
+  // piece, i.e. row (l >> 4), physical chunk (l & 15), so it FETCHES the logical chunk that the image's XOR puts there.  Wave w takes
+  // pieces w and w + 8 (keys 4w + r and 32 + 4w + r: the same (key & 15) and (key & 3), hence ONE per-lane offset per tensor; the
+  // second piece and the tile advance are added to the VECTOR offset — a raw buffer's range check does not see the scalar offset, and
+  // rows past the end of the sequence must read as zeros).
+  const int dr = lane >> 4, dpc = lane & 15, dkey = 4 * wave + dr;
+  const int klc = dpc ^ (dkey & 15), vlc = dpc ^ ((dkey & 3) << 2);
+  const uint32_t kdo = (HD == 64 && klc >= 8) ? 0x80000000u : (uint32_t)(dkey * p.ldk + klc * 8) * 2u;
+  const uint32_t vdo = (HD == 64 && vlc >= 8) ? 0x80000000u : (uint32_t)(dkey * p.ldv + vlc * 8) * 2u;
+  auto dma_k = [&](const int t, const int buf) {
+    const uint32_t adv = (uint32_t)(t * 64 * p.ldk) * 2u;
+    char* dst = smem + buf * F2_TB + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, LDS_PTR(dst), 16, kdo + adv, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, LDS_PTR(dst + 8192), 16, kdo + adv + (uint32_t)(32 * p.ldk) * 2u, 0, 0, 0);
+  };
+  auto dma_v = [&](const int t, const int buf) {
+    const uint32_t adv = (uint32_t)(t * 64 * p.ldv) * 2u;
+    char* dst = smem + 2 * F2_TB + buf * F2_TB + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(dst), 16, vdo + adv, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(dst + 8192), 16, vdo + adv + (uint32_t)(32 * p.ldv) * 2u, 0, 0, 0);
+  };
+#endif
   u32x4 kr0, kr1, vr0, vr1;
 #if F2_TOUCH
   uint32_t tk0 = 0, tv0 = 0;
@@ -511,12 +539,17 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     }
   };
 
-  // ---- prologue: K(0) -> LDS; K(1) and V(0) in flight towards the staging registers
+  // ---- prologue: K(0) -> LDS; K(1) and V(0) in flight towards the staging registers (F2_DMA: issued at the top of iteration 0)
+#if F2_DMA
+  if (ntiles > 0) dma_k(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   if (ntiles > 0) {
     gload_k(0); write_k(0);
     if (ntiles > 1) gload_k(1);
     gload_v(0);
   }
+#endif
   __syncthreads();
   F2_STAMP(tbase + 1);
 
@@ -525,7 +558,16 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // V(j+1) are re-issued at once: the loads get a whole iteration to land, the ds_writes overlap this iteration's MFMAs, and
   // only the barrier follows the last MFMA (written before the barrier they sat serialised behind the MFMAs).
   for (int j = 0; j <= ntiles; ++j) {
+#if F2_DMA
+    // K(j+1) and V(j) go straight into the buffers whose last readers finished before the barrier that ended iteration j-1; they are
+    // first read after the barrier that ends THIS iteration (vmcnt(0) in front of it): a whole iteration to land, nothing to wait for
+    // inside it
     if (F2_ABL != 5) {
+      if (j + 1 < ntiles) dma_k(j + 1, (j + 1) & 1);
+      if (j < ntiles) dma_v(j, j & 1);
+    }
+#endif
+    if (F2_ABL != 5 && !F2_DMA) {
       if (j + 1 < ntiles) write_k((j + 1) & 1);
       if (j < ntiles) write_v(j & 1);
 #if F2_TOUCH
@@ -571,7 +613,11 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vaddr[dt] ^= F2_TB;
     }
+#if F2_DMA
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of K(j+1), V(j) have landed; my reads of K(j), V(j-1) are done
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     if (F2_ABL != 1) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     F2_STAMP(tbase + 2 + j);
