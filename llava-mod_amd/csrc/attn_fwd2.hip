@@ -61,6 +61,15 @@ __device__ unsigned long long f2_trace_buf[8 * 128];
 #endif                              //   staging registers, no ds_write issue slots, no in-loop wait on a register load (0: the round-2 path —
                                     //   global -> 16 VGPRs -> ds_write_b128 one iteration later; the timing ablation "no staging" read +18 %
                                     //   at B16 S2048 causal, profiles/r05_attn_ablation.md)
+#ifndef F2_RING
+#define F2_RING 2                   // K / V tile buffers per tensor.  3 (LDS-DMA only): a tile is requested TWO iterations before its first
+#endif                              //   read and the end-of-iteration wait leaves the newest request in flight (counted vmcnt) — measured
+                                    //   -1 ... -3.5 % against 2 (one iteration ahead, vmcnt(0) in front of the barrier): the requests are not
+                                    //   late (profiles/r05_attn_fwd_variants.jsonl), the 96 KiB ring and its address stepping only cost
+#define F2_VBASE (F2_RING * F2_TB)  // V buffers follow the K buffers
+#ifndef F2_PRIO
+#define F2_PRIO 0                   // 1: s_setprio 1 for waves 4-7 (the later-dispatched wave of every SIMD) for the whole block
+#endif
 #ifndef F2_TOUCH
 #define F2_TOUCH 0                  // > 0: L2 touch of the K / V tiles this many iterations ahead of their register loads
 #endif
@@ -315,6 +324,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     }
   }
   acc_zero();
+  if (F2_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
   float mrun = -INFINITY, lrun = 0.f;
 
   // ---- staging: 2 x 16-byte chunks of K and of V per thread and tile
@@ -348,7 +358,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   };
   auto dma_v = [&](const int t, const int buf) {
     const uint32_t adv = (uint32_t)(t * 64 * p.ldv) * 2u;
-    char* dst = smem + 2 * F2_TB + buf * F2_TB + wave * 1024;
+    char* dst = smem + F2_VBASE + buf * F2_TB + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(dst), 16, vdo + adv, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(dst + 8192), 16, vdo + adv + (uint32_t)(32 * p.ldv) * 2u, 0, 0, 0);
   };
@@ -372,8 +382,8 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
     *(u32x4*)(smem + buf * F2_TB + kwo + 8192) = kr1;
   };
   auto write_v = [&](int buf) {
-    *(u32x4*)(smem + 2 * F2_TB + buf * F2_TB + vwo) = vr0;
-    *(u32x4*)(smem + 2 * F2_TB + buf * F2_TB + vwo + 8192) = vr1;
+    *(u32x4*)(smem + F2_VBASE + buf * F2_TB + vwo) = vr0;
+    *(u32x4*)(smem + F2_VBASE + buf * F2_TB + vwo + 8192) = vr1;
   };
 
   // ---- operand read addresses
@@ -491,7 +501,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // PV: a previous tile exists.  SM: this wave computes tile j.
   auto phase_b = [&](auto masked_t, auto pv_t, auto sm_t, const int mthr) {   // vaddr points into the V buffer of tile j-1
     constexpr bool PV = decltype(pv_t)::value, SM = decltype(sm_t)::value;
-    const char* vbp = smem + 2 * F2_TB;
+    const char* vbp = smem + F2_VBASE;
     bf16x8 vf[F2_DEPTH + 1];
     if constexpr (PV) {
 #pragma unroll
@@ -542,6 +552,10 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // ---- prologue: K(0) -> LDS; K(1) and V(0) in flight towards the staging registers (F2_DMA: issued at the top of iteration 0)
 #if F2_DMA
   if (ntiles > 0) dma_k(0, 0);
+  if (F2_RING == 3) {                 // K(1) and V(0) too: iteration 0 requests K(2), V(1)
+    if (ntiles > 1) dma_k(1, 1);
+    if (ntiles > 0) dma_v(0, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
   if (ntiles > 0) {
@@ -557,14 +571,24 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // to LDS right AFTER the barrier that ended iteration j-1 (their buffers' last readers are done) and the loads of K(j+2),
   // V(j+1) are re-issued at once: the loads get a whole iteration to land, the ds_writes overlap this iteration's MFMAs, and
   // only the barrier follows the last MFMA (written before the barrier they sat serialised behind the MFMAs).
+#if F2_RING == 3
+  int kring0 = 0, kring2 = 2, vring0 = 0, vring1 = 1;          // slots of K(j), K(j+2), V(j-1) (from j = 1), V(j+1)
+#endif
   for (int j = 0; j <= ntiles; ++j) {
 #if F2_DMA
     // K(j+1) and V(j) go straight into the buffers whose last readers finished before the barrier that ended iteration j-1; they are
     // first read after the barrier that ends THIS iteration (vmcnt(0) in front of it): a whole iteration to land, nothing to wait for
     // inside it
     if (F2_ABL != 5) {
+#if F2_RING == 3
+      // K(j+2) -> the slot K(j-1) left, V(j+1) -> the slot V(j-2) left (their last readers finished before the barrier that ended
+      // iteration j-1); first read two barriers from now
+      if (j + 2 < ntiles) dma_k(j + 2, kring2);
+      if (j + 1 < ntiles) dma_v(j + 1, vring1);
+#else
       if (j + 1 < ntiles) dma_k(j + 1, (j + 1) & 1);
       if (j < ntiles) dma_v(j, j & 1);
+#endif
     }
 #endif
     if (F2_ABL != 5 && !F2_DMA) {
@@ -606,6 +630,30 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
       phase_b(F{}, T{}, F{}, mthr);
     }
     if (j == ntiles) break;
+#if F2_RING == 3
+    // K(j) sat in slot j % 3, V(j-1) in slot (j-1) % 3: step the read bases round the ring (kstep / vstep: +F2_TB, or -2 F2_TB at the wrap)
+    {
+      const int kstep = (kring0 == 2) ? -2 * F2_TB : F2_TB;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kaddr[ks] += kstep;
+      kring0 = (kring0 == 2) ? 0 : kring0 + 1;
+      kring2 = (kring2 == 2) ? 0 : kring2 + 1;
+      if (j >= 1) {
+        const int vstep = (vring0 == 2) ? -2 * F2_TB : F2_TB;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vaddr[dt] += vstep;
+        vring0 = (vring0 == 2) ? 0 : vring0 + 1;
+      }
+      vring1 = (vring1 == 2) ? 0 : vring1 + 1;
+    }
+    // everything requested BEFORE this iteration has landed; what this iteration requested (0, 2 or 4 wave-instructions) stays in flight
+    {
+      const int mine = ((F2_ABL != 5 && j + 2 < ntiles) ? 2 : 0) + ((F2_ABL != 5 && j + 1 < ntiles) ? 2 : 0);
+      if (mine == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (mine == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+#else
     // K(j) sat in buffer j&1, K(j+1) sits in the other one; V(j-1) sat in (j-1)&1, V(j) sits in j&1: flip the bases
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) kaddr[ks] ^= F2_TB;
@@ -613,7 +661,9 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vaddr[dt] ^= F2_TB;
     }
-#if F2_DMA
+#endif
+#if F2_RING == 3
+#elif F2_DMA
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of K(j+1), V(j) have landed; my reads of K(j), V(j-1) are done
 #else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -685,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
 
 void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream, int hd) {
   static bool attr = false;
-  const int lds = 4 * F2_TB;
+  const int lds = 2 * F2_RING * F2_TB;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -195,7 +195,8 @@ class DataParallel:
     experts.  `armed=False` (non-final micro-batches of a gradient-accumulation window) defers everything to `finish()`
     of the final micro-batch."""
 
-    def __init__(self, bucket_bytes=512 << 20, overlap=True, zero2=False, grad_dtype=torch.float32, min_shard_numel=1 << 16):
+    def __init__(self, bucket_bytes=512 << 20, overlap=True, zero2=False, grad_dtype=torch.float32, min_shard_numel=1 << 16,
+                 native=None):
         # LMOD_DP_FORCE=1: run the whole exchange path (RCCL collectives, shard plan, all-gather) even in a world of ONE rank —
         # how the N>1 code is exercised on a single-GPU box (tests/test_step_parity_gpu.py)
         self.enabled = dist.is_available() and dist.is_initialized() and (
@@ -207,6 +208,12 @@ class DataParallel:
         self.zero2 = bool(zero2) and self.enabled
         self.grad_dtype = grad_dtype
         self.min_shard = min_shard_numel
+        # native: exchanges over the WORLD go through the C-ABI collectives of the kernel library (csrc/comm.hip: lmod_allreduce_grads /
+        # lmod_reduce_scatter_grads / lmod_allgather_params, one RCCL communicator created from an id that rank 0 broadcasts) on a side
+        # stream ordered behind the compute stream by an event — the boundary a host without torch.distributed binds,
+        # here driven by the same engine.  Sub-group exchanges (expert-data-parallel spans) stay on torch.distributed.  LMOD_DP_NATIVE=1.
+        self.native = (os.environ.get("LMOD_DP_NATIVE") == "1") if native is None else bool(native)
+        self._ncomm = self._nstream = None
         self.armed = True                 # set False on non-final micro-batches of a gradient-accumulation window
         self._handles, self._done, self._map, self._bias = [], set(), {}, {}   # _done holds (id(obj), kind) of sent spans
         self._castback = []               # bf16 exchange: (lo, hi) chunks to cast back to fp32 once the collective is done
@@ -260,6 +267,44 @@ class DataParallel:
         return info["lo"], info["hi"], (info["sharded"] or info["grank"] == 0)
 
     # ---- exchange --------------------------------------------------------------------------------------------------
+    def native_comm(self):
+        """The process's C-ABI communicator over the world (created on first use: rank 0 draws the id, everybody receives it over the
+        existing process group) and the side stream its collectives are enqueued on."""
+        if self._ncomm is None:
+            from . import comm
+            uid = [comm.unique_id() if self.rank == 0 else None]
+            if dist.get_world_size() > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self._ncomm = comm.NativeComm(uid[0], self.rank, self.world)
+            self._nstream = torch.cuda.Stream()
+        return self._ncomm, self._nstream
+
+    class _StreamHandle:
+        """`wait()` of a collective enqueued on the native side stream: the current stream waits for everything enqueued there so far."""
+
+        def __init__(self, stream):
+            self.ev = torch.cuda.Event()
+            self.ev.record(stream)
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def _send_native(self, flat, info):
+        nc, ns = self.native_comm()
+        off, n = info["off"], info["n"]
+        ev = torch.cuda.Event()
+        ev.record()                                           # behind the weight-gradient GEMMs enqueued so far on the compute stream
+        with torch.cuda.stream(ns):
+            ns.wait_event(ev)
+            if info["sharded"]:
+                comm_count("reduce_scatter", flat[off:off + n])
+                nc.reduce_scatter_(flat[off:off + n])         # chunk `rank` of the sum lands in place at off + rank * n / world = info["lo"]
+            else:
+                for a in range(off, off + n, self.bucket):
+                    comm_count("all_reduce", flat[a:min(a + self.bucket, off + n)])
+                    nc.allreduce_(flat[a:min(a + self.bucket, off + n)])
+        self._handles.append(DataParallel._StreamHandle(ns))
+
     def _send(self, obj, kind):
         info = self.plan[(id(obj), kind)]
         self._done.add((id(obj), kind))
@@ -271,6 +316,8 @@ class DataParallel:
             K.cast_f32_bf16(flat[off:off + n], self._gbf[off:off + n])
             flat = self._gbf
             self._castback.append((info["lo"], info["hi"]))
+        if self.native and g is None and flat.is_cuda:
+            return self._send_native(flat, info)
         if info["sharded"]:
             comm_count("reduce_scatter", flat[off:off + n])
             self._handles.append(dist.reduce_scatter_tensor(flat[info["lo"]:info["hi"]], flat[off:off + n],
@@ -489,6 +536,15 @@ class HipAdamW:
             if info["sharded"]:
                 full = self.gb.pflat[off:off + info["n"]]
                 comm_count("all_gather", full)
+                if self.dp.native and info["group"] is None and full.is_cuda:      # the C-ABI collective (lmod_allgather_params), in place
+                    nc, ns = self.dp.native_comm()
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(ns):
+                        ns.wait_event(ev)
+                        nc.allgather_(full)
+                    handles.append(DataParallel._StreamHandle(ns))
+                    continue
                 handles.append(dist.all_gather_into_tensor(full, self.gb.pflat[lo:hi], group=info["group"], async_op=True))
         for h in handles:
             h.wait()

@@ -188,6 +188,15 @@ class MoE(nn.Module):
         pl = ops.ep_live_row_plan(host[0].reshape(ep, El), host[1].reshape(ep, El), C, x.device)
         self.last_ep_plan = pl
         packed = ops.RowGather.apply(disp, pl.send_idx, pl.send_inv)                         # [Ls, H] live rows only
+        nchunk = int(getattr(self, "ep_chunks", 0) or os.environ.get("LMOD_EP_CHUNKS", "1"))
+        if El == 1 and nchunk > 1 and group is not None:
+            # ONE local expert, pipelined: the exchange of chunk c+1 under the expert GEMMs of chunk c, both directions, forward and
+            # backward (ops.chunked_expert_exchange).  Every chunk runs the block (or its empty stand-in) so that the weight-gradient
+            # hooks fire the same number of times on every rank.
+            blk = lambda rows: (ops.MLPBlock if rows.shape[0] > 0 else ops.EmptyExpertPass).apply(rows, spec, *expert_params)
+            back_p = ops.chunked_expert_exchange(packed, pl.in_splits, pl.out_splits, group, blk, nchunk)
+            back = ops.RowGather.apply(back_p, pl.send_inv, pl.send_idx)
+            return ops.MoECombine.apply(back, w1, w2, st), l_aux, counts
         recv_p = ops.AllToAllRows.apply(packed, pl.in_splits, pl.out_splits, group)          # [Lr, H]
         if El == 1:
             # ONE local expert (config 5: 8 experts on 8 ranks): the packed live rows ARE its input — no capacity slabs on the

@@ -785,6 +785,27 @@ class AllToAll(torch.autograd.Function):
         return out, None
 
 
+_NATIVE_WORLD = {}
+
+
+def _native_world_comm(group, x):
+    """LMOD_DP_NATIVE=1 and an expert-parallel group that IS the world (config 5: 8 experts on 8 ranks): the C-ABI communicator of the
+    kernel library (llavamod.comm.NativeComm) instead of torch.distributed; None otherwise."""
+    import torch.distributed as dist
+    if os.environ.get("LMOD_DP_NATIVE") != "1" or not x.is_cuda or x.dtype != BF16:
+        return None
+    if group is not dist.group.WORLD and dist.get_world_size(group) != dist.get_world_size():
+        return None
+    key = x.device.index
+    if key not in _NATIVE_WORLD:
+        from . import comm
+        uid = [comm.unique_id() if dist.get_rank() == 0 else None]
+        if dist.get_world_size() > 1:
+            dist.broadcast_object_list(uid, src=0)
+        _NATIVE_WORLD[key] = comm.NativeComm(uid[0], dist.get_rank(), dist.get_world_size())
+    return _NATIVE_WORLD[key]
+
+
 class AllToAllRows(torch.autograd.Function):
     """Unequal-split all_to_all_single of PACKED live rows [L, H]: rank d receives `in_splits[d]` rows of x and this rank
     receives `out_splits[s]` rows from rank s (host ints).  Backward is the reverse exchange with the splits swapped.
@@ -798,8 +819,11 @@ class AllToAllRows(torch.autograd.Function):
         import torch.distributed as dist
         from .engine import comm_count
         x = x.contiguous()
-        out = torch.empty((sum(out_splits), x.shape[1]), device=x.device, dtype=x.dtype)
         comm_count("all_to_all", x)
+        nat = _native_world_comm(group, x)
+        if nat is not None:                                      # the C-ABI exchange (lmod_moe_all_to_all: grouped send / recv of the live rows)
+            return nat.moe_all_to_all(x, ctx.in_splits, ctx.out_splits)
+        out = torch.empty((sum(out_splits), x.shape[1]), device=x.device, dtype=x.dtype)
         dist.all_to_all_single(out, x, output_split_sizes=ctx.out_splits, input_split_sizes=ctx.in_splits, group=group)
         return out
 
@@ -810,10 +834,126 @@ class AllToAllRows(torch.autograd.Function):
         import torch.distributed as dist
         from .engine import comm_count
         g = g.contiguous()
-        out = torch.empty((sum(ctx.in_splits), g.shape[1]), device=g.device, dtype=g.dtype)
         comm_count("all_to_all", g)
+        nat = _native_world_comm(ctx.group, g)
+        if nat is not None:
+            return nat.moe_all_to_all(g, ctx.out_splits, ctx.in_splits), None, None, None
+        out = torch.empty((sum(ctx.in_splits), g.shape[1]), device=g.device, dtype=g.dtype)
         dist.all_to_all_single(out, g, output_split_sizes=ctx.in_splits, input_split_sizes=ctx.out_splits, group=ctx.group)
         return out, None, None, None
+
+
+class _A2AStart(torch.autograd.Function):
+    """First half of an ASYNCHRONOUS unequal-split all-to-all of packed rows: the exchange is handed to the backend (RCCL runs it on its
+    own stream, ordered after this stream's work so far) and the not-yet-complete output is returned; `_A2AWait` completes it.  The
+    handle travels in `box`.  Backward: waits for the reverse exchange that `_A2AWait.backward` started."""
+
+    @staticmethod
+    def forward(ctx, x, in_splits, out_splits, group, box):
+        import torch.distributed as dist
+        from .engine import comm_count
+        ctx.box = box
+        box["splits"] = (list(in_splits), list(out_splits), group)
+        x = x.contiguous()
+        out = torch.empty((sum(out_splits), x.shape[1]), device=x.device, dtype=x.dtype)
+        comm_count("all_to_all", x)
+        box["fwd"] = dist.all_to_all_single(out, x, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group,
+                                            async_op=True)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.box.pop("bwd", None)
+        if w is not None:
+            w.wait()
+        return ctx.box.pop("bwd_out"), None, None, None, None
+
+
+class _A2AWait(torch.autograd.Function):
+    """Second half: this stream waits for the exchange `_A2AStart` launched.  Backward: launches the reverse exchange of the incoming
+    gradient asynchronously (it runs under whatever backward work autograd schedules next) and hands the pending buffer on."""
+
+    @staticmethod
+    def forward(ctx, out, box):
+        ctx.box = box
+        w = box.pop("fwd", None)
+        if w is not None:
+            w.wait()
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        from .engine import comm_count
+        in_splits, out_splits, group = ctx.box["splits"]
+        g = g.contiguous()
+        gout = torch.empty((sum(in_splits), g.shape[1]), device=g.device, dtype=g.dtype)
+        comm_count("all_to_all", g)
+        ctx.box["bwd"] = dist.all_to_all_single(gout, g, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group,
+                                                async_op=True)
+        ctx.box["bwd_out"] = gout
+        return g, None               # (a token of the right shape: `_A2AStart.backward` returns the exchanged buffer once it has landed)
+
+
+class _SplitRows(torch.autograd.Function):
+    """x [L, H] -> its row chunks [starts[c], starts[c + 1]) (views); backward: the chunks' gradients concatenated (a copy — torch's
+    own slice backward would zero-fill a full-size tensor per chunk and ADD them)."""
+
+    @staticmethod
+    def forward(ctx, x, starts):
+        ctx.starts, ctx.H, ctx.dt, ctx.dev = list(starts), x.shape[1], x.dtype, x.device
+        return tuple(x.narrow(0, starts[c], starts[c + 1] - starts[c]) for c in range(len(starts) - 1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        parts = [g if g is not None else torch.zeros((ctx.starts[c + 1] - ctx.starts[c], ctx.H), device=ctx.dev, dtype=ctx.dt)
+                 for c, g in enumerate(gs)]
+        return torch.cat(parts, dim=0), None
+
+
+def chunked_expert_exchange(packed, in_splits, out_splits, group, block_fn, nchunk):
+    """The expert-parallel round trip of ONE local expert — all-to-all of the packed live rows, the expert block on what arrives,
+    all-to-all back (`MoE._forward_expert_parallel`) — as a PIPELINE over `nchunk` row chunks (VERDICT r04 next #9b): the exchange of
+    chunk c+1 is in flight while the expert GEMMs of chunk c run, and chunk c's results travel back under chunk c+1's GEMMs; the
+    backward overlaps the same way (the asynchronous halves `_A2AStart` / `_A2AWait` put every reverse exchange under the next
+    chunk's backward GEMMs).  Every (source, destination) block of rows is cut at the same relative positions on both sides —
+    chunk c of a block of n rows is rows [n c / nchunk, n (c + 1) / nchunk) — so no extra count exchange is needed.  The expert
+    block is row-wise, so the forward result equals the unchunked exchange bit for bit; the expert's weight gradient accumulates
+    chunk by chunk.  packed [sum(in_splits), H] ordered by destination; returns the same shape and order."""
+    import numpy as np
+    ep = len(in_splits)
+    cut = lambda n, c: (n * c) // nchunk
+    # permutation packed order (dest-major) -> chunk-major: [chunk 0: dest 0 part, dest 1 part, ...][chunk 1: ...]
+    off = np.concatenate([[0], np.cumsum(in_splits)]).astype(np.int64)
+    perm, cin, cout = [], [], []
+    for c in range(nchunk):
+        cin.append([cut(in_splits[d], c + 1) - cut(in_splits[d], c) for d in range(ep)])
+        cout.append([cut(out_splits[s_], c + 1) - cut(out_splits[s_], c) for s_ in range(ep)])
+        for d in range(ep):
+            perm.append(np.arange(off[d] + cut(in_splits[d], c), off[d] + cut(in_splits[d], c + 1), dtype=np.int32))
+    perm = np.concatenate(perm) if perm else np.zeros(0, dtype=np.int32)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size, dtype=np.int32)
+    dev = packed.device
+    perm_t, inv_t = torch.from_numpy(perm).to(dev), torch.from_numpy(inv).to(dev)
+    x = RowGather.apply(packed, perm_t, inv_t)                       # chunk-major rows
+    starts = [0]
+    for ci in cin:
+        starts.append(starts[-1] + sum(ci))
+    xs = _SplitRows.apply(x, starts)
+    boxes_f, boxes_b = [dict() for _ in range(nchunk)], [dict() for _ in range(nchunk)]
+    pend = [None] * nchunk
+    pend[0] = _A2AStart.apply(xs[0], cin[0], cout[0], group, boxes_f[0])
+    backs = []
+    for c in range(nchunk):
+        if c + 1 < nchunk:                                           # chunk c+1 leaves while chunk c is computed
+            pend[c + 1] = _A2AStart.apply(xs[c + 1], cin[c + 1], cout[c + 1], group, boxes_f[c + 1])
+        rows = _A2AWait.apply(pend[c], boxes_f[c])
+        y = block_fn(rows)
+        backs.append(_A2AStart.apply(y, cout[c], cin[c], group, boxes_b[c]))      # travels back under chunk c+1's GEMMs
+    outs = [_A2AWait.apply(backs[c], boxes_b[c]) for c in range(nchunk)]
+    y_all = torch.cat(outs, dim=0) if nchunk > 1 else outs[0]       # (a copy of [rows, H] bf16, no arithmetic)
+    return RowGather.apply(y_all, inv_t, perm_t)                     # back to the packed (destination-major) order
 
 
 def ep_live_row_plan(used, recv, C, device):

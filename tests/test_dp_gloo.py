@@ -559,3 +559,66 @@ def test_four_rank_gloo_starved_expert_keeps_collective_order():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = sorted(q.get(timeout=5) for _ in range(4))
     assert got == [(r, "ok") for r in range(4)]
+
+
+def _chunked_ep_worker(rank, world, port, q):
+    """The pipelined expert-parallel round trip (ops.chunked_expert_exchange: exchange of chunk c+1 under the expert block of chunk c,
+    both directions) against the unchunked one (AllToAllRows -> block -> AllToAllRows) over gloo: same outputs, same input gradients,
+    same parameter gradient, for 1 (degenerate), 2, 3 and 5 chunks, unequal and ZERO split sizes, a rank that receives nothing."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LMOD_DIST_BACKEND="gloo")
+    from llavamod import ops
+    from llavamod.engine import expert_parallel_group, init_distributed
+    import llavamod.kernels as K
+    init_distributed()
+    grp = expert_parallel_group(world)
+
+    def gather_rows(src_a, src_b, idx, Hh):
+        out = torch.zeros((idx.numel(), Hh), dtype=src_a.dtype)
+        m = idx >= 0
+        out[m] = src_a[idx[m].long()]
+        return out
+    K.gather_rows = gather_rows
+    H = 6
+    cases = {"uneven": [[3, 7, 0][:world], [5, 1, 4][:world], [0, 2, 9][:world]], "starved": [[4, 0, 3][:world], [6, 0, 2][:world], [1, 0, 5][:world]]}
+    for name, table in cases.items():                            # table[src][dst] rows
+        in_splits = table[rank][:world]
+        out_splits = [table[s][rank] for s in range(world)]
+        g = torch.Generator().manual_seed(17 + rank)
+        base = torch.randn(sum(in_splits), H, generator=g, dtype=torch.float64)
+        w = torch.randn(H, H, generator=torch.Generator().manual_seed(5), dtype=torch.float64)       # the "expert": same on every rank here
+        cot = torch.randn(sum(in_splits), H, generator=g, dtype=torch.float64)
+
+        def run(nchunk):
+            x = base.clone().requires_grad_(True)
+            wp = w.clone().requires_grad_(True)
+            block = lambda rows: torch.tanh(rows @ wp) * 1.5 + rows          # row-wise, like the expert FFN
+            if nchunk == 0:
+                recv = ops.AllToAllRows.apply(x, in_splits, out_splits, grp)
+                y = ops.AllToAllRows.apply(block(recv), out_splits, in_splits, grp)
+            else:
+                y = ops.chunked_expert_exchange(x, in_splits, out_splits, grp, block, nchunk)
+            (y * cot).sum().backward()
+            return y.detach(), x.grad, wp.grad
+        y0, gx0, gw0 = run(0)
+        for nchunk in (1, 2, 3, 5):
+            y, gx, gw = run(nchunk)
+            # (a host BLAS may block a [rows, H] product differently for another row count: equal to fp64 rounding, not bitwise)
+            assert torch.allclose(y, y0, rtol=1e-13, atol=1e-13) and torch.allclose(gx, gx0, rtol=1e-13, atol=1e-13), (name, nchunk)
+            assert torch.allclose(gw, gw0, rtol=1e-12, atol=1e-12), (name, nchunk)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_three_rank_gloo_chunked_expert_exchange_equals_unchunked():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunked_ep_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(3)) == [(r, "ok") for r in range(3)]

@@ -95,6 +95,18 @@ def _ep_worker(rank, world, port, q):
                 rv = g_ref[n.replace(f"deepspeed_experts.{i}.", f"deepspeed_experts.{rank * nl + i}.")]
             err = (gv - rv).abs().max().item()
             assert err <= 2e-3 * max(1e-6, rv.abs().max().item()), (live, n, err, rv.abs().max().item())
+        if E == 2 and live:
+            # the same layer with its round trip PIPELINED over 2 and 3 row chunks (exchange of chunk c+1 under the expert GEMMs of chunk
+            # c, ops.chunked_expert_exchange): the expert block is row-wise, so outputs, aux loss and input gradients are bit-identical
+            # to the unchunked exchange; the expert weight gradients accumulate chunk by chunk (fp32: equal to rounding of the sums)
+            for nchunk in (2, 3):
+                epc = make(2)
+                epc.ep_live_rows, epc.ep_chunks = True, nchunk
+                oc, lc, cc, gxc = run(epc, x_me, d_me)
+                assert torch.equal(oc, o) and torch.equal(lc, l) and torch.equal(cc, c) and torch.equal(gxc, gx), nchunk
+                for n, gv in grads(epc).items():
+                    rv = g_ep[n]
+                    assert (gv - rv).abs().max().item() <= 1e-4 * max(1e-6, rv.abs().max().item()), (nchunk, n)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
