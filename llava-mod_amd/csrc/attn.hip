@@ -650,6 +650,9 @@ extern "C" {
 // Q [B*S, ldq] (head h at column h*hd), K/V [B*S, ldk/ldv] (kv head at column hk*hd); O [B*S, ldo];
 // lse [B, nh, S] fp32 (natural log of the scaled-score partition function; may be NULL).
 // seqlens [B] i32 or NULL: keys >= seqlens[b] are masked.
+#ifndef LMOD_ATTN_FWD_DEFAULT
+#define LMOD_ATTN_FWD_DEFAULT 2
+#endif
 int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens,
                   const int* cu_seqlens, int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
                   int causal, hipStream_t stream) {
@@ -662,8 +665,10 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
   if (cu_seqlens && (hd != 128 || seqlens)) return LMOD_EUNSUPPORTED;      // packed (varlen) layout: the hd-128 kernels only
-  static int fwd_ver = -1;         // LMOD_ATTN_FWD=1: the round-1 16x16x32 kernel for hd 128 as well (A/B runs)
-  if (fwd_ver < 0) { const char* e = getenv("LMOD_ATTN_FWD"); fwd_ver = e ? atoi(e) : 2; }
+  // LMOD_ATTN_FWD (read once): 3 = the one-wave-per-SIMD kernel of round 5 (attn_fwd3.hip: 4 waves x 64 queries) for hd 128,
+  // 2 = the 8-wave 32x32x16 kernel (attn_fwd2.hip), 1 = the round-1 16x16x32 kernel for hd 128 as well (A/B runs)
+  static const int fwd_ver = [] { const char* e = getenv("LMOD_ATTN_FWD"); return e ? atoi(e) : LMOD_ATTN_FWD_DEFAULT; }();
+  if (hd == 128 && fwd_ver == 3) { lmod_launch_attn_fwd3(p, causal, stream); return lmod_launch_status(); }
   if (hd == 128 && (fwd_ver != 1 || cu_seqlens)) { lmod_launch_attn_fwd2(p, causal, stream); return lmod_launch_status(); }
   // head dim 64 (round 4: the Qwen2-0.5B student, the CLIP tower): the 32x32x16 pipelined kernel with the upper feature half absent;
   // LMOD_ATTN_FWD=1 keeps the generic 16x16x32 kernel (A/B runs, tests)

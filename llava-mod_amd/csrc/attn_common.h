@@ -34,5 +34,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // hd-128 forward, 32x32x16-MFMA software-pipelined kernel (attn_fwd2.hip)
 void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream, int hd = 128);
 
+// hd-128 forward, one wave per SIMD with 64 query rows per wave (attn_fwd3.hip, round 5)
+void lmod_launch_attn_fwd3(const AttnP& p, int causal, hipStream_t stream);
+
 // hd-128 backward (dQ and dK/dV kernels), one wave per SIMD with 256 asm-owned accumulators (attn_bwd2.hip)
 void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream);

@@ -874,6 +874,19 @@ def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
     close(dqkv[:, (nh + nkv) * hd:].reshape(B, S, nkv, hd), vf.grad, "attn dV", rtol=2 ** -5, afrac=2 ** -6)
 
 
+def test_attn_forward_one_wave_per_simd_kernel_passes_the_same_tests():
+    """attn_fwd3.hip (round 5: 4 waves x 64 queries, one wave per SIMD, O^T and Q in asm-owned accumulators, K / V by LDS-DMA) is selected
+    by LMOD_ATTN_FWD=3, read once per process: every attention test of this file — forward values and lse against fp32 torch, and the
+    backward fed by ITS outputs — is re-run in a child process under the switch."""
+    import subprocess
+    if os.environ.get("LMOD_ATTN_FWD"):
+        pytest.skip("already inside a run that selects a forward kernel")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "attn and not one_wave"],
+                       env=dict(os.environ, LMOD_ATTN_FWD="3"), capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-600:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
 def test_attn_online_softmax_rescale_branch():
     # force a late, large max: one key far down the sequence dominates one query row (guide rule 26)
     B, S, nh, hd = 1, 512, 1, 128

@@ -853,8 +853,7 @@ def _nccl_zero2_worker(rank, world, port, q):
             opt.step(grad_scale=1.0 / world, clear_grads=True)
         torch.cuda.synchronize()
         if mode.endswith("native"):
-            assert dp._ncomm is not None
-            engine_comm_calls["native"] = engine_comm_calls.get("native", 0) + len([1 for _ in range(3)]) * 2
+            engine_comm_calls[mode] = dp._ncomm is not None      # the communicator of csrc/comm.hip was created and used
         res[mode] = {k: v.detach().float().cpu() for k, v in student.state_dict().items()}
     bad = [k for k in res["allreduce"] if not torch.allclose(res["allreduce"][k], res["zero2"][k], rtol=0, atol=1e-6)]
     dist.barrier()
@@ -906,14 +905,12 @@ def _rccl_world1_worker(port, q):
                 opt.step(grad_scale=0.5, clear_grads=True)
         torch.cuda.synchronize()
         if mode.endswith("native"):
-            assert dp._ncomm is not None
-            engine_comm_calls["native"] = engine_comm_calls.get("native", 0) + len([1 for _ in range(3)]) * 2
+            engine_comm_calls[mode] = dp._ncomm is not None      # the communicator of csrc/comm.hip was created and used
         res[mode] = {k: v.detach().float().cpu() for k, v in student.state_dict().items()}
     bad = {}
     for mode in ("allreduce", "zero2", "allreduce_native", "zero2_native"):   # one rank: the exchange is the identity -> identical weights
         bad[mode] = [k for k in res["plain"] if not torch.equal(res["plain"][k], res[mode][k])]
-    n_native = sum(engine_comm_calls.get(k, 0) for k in ("native",))
-    bad["native_used"] = [] if n_native >= 6 else [f"only {n_native} native collectives were issued"]
+    bad["native_used"] = [m_ for m_ in ("allreduce_native", "zero2_native") if not engine_comm_calls.get(m_)]
     far = [k for k in res["plain"] if (res["plain"][k] - res["zero2_bf16"][k]).abs().max() > 2.5e-3]   # lr-sized Adam steps
     bad["zero2_bf16"] = far
     # the expert-parallel exchange through RCCL (VERDICT r03 next #6c): with LMOD_FORCE_DIST the decomposed MoE path sends its

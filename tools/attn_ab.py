@@ -33,10 +33,19 @@ for tag, B, S, nh, causal, ragged in (("c_b16_nh16", 16, 2048, 16, True, False),
         res["bwd_" + tag] = round(2.5 * fl / t / 1e12, 1)
 print("RES " + json.dumps(res))
 ''' % (ROOT, ROOT, bwd)
-libs = [("shipped", os.path.join(ROOT, "llava-mod_amd", "llavamod", "_lib", "liblmod_hip.so"))] + \
-       [(n, os.path.join(ROOT, "alt_libs", f"liblmod_{n}.so")) for n in names]
-for rnd in range(3):
-    for name, path in libs:
-        out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, LMOD_HIP_LIB=path), capture_output=True, text=True, timeout=300)
+SHIPPED = os.path.join(ROOT, "llava-mod_amd", "llavamod", "_lib", "liblmod_hip.so")
+# an arm is a library build (alt_libs/liblmod_<name>.so) or, spelled env:VAR=value, the shipped library under an environment switch
+# (name@VAR=value: that library build under the switch)
+def arm(n):
+    if n.startswith("env:"):
+        return (n, SHIPPED, dict([n[4:].split("=", 1)]))
+    if "@" in n:
+        lib, ev = n.split("@", 1)
+        return (n, os.path.join(ROOT, "alt_libs", f"liblmod_{lib}.so"), dict([ev.split("=", 1)]))
+    return (n, os.path.join(ROOT, "alt_libs", f"liblmod_{n}.so"), {})
+libs = [("shipped", SHIPPED, {})] + [arm(n) for n in names]
+for rnd in range(int(os.environ.get('ATTN_AB_ROUNDS', '3'))):
+    for name, path, extra in libs:
+        out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, LMOD_HIP_LIB=path, **extra), capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.split("\n") if l.startswith("RES ")]
         print(json.dumps({"build": name, "round": rnd, **(json.loads(line[0][4:]) if line else {"error": out.stderr[-300:]})}), flush=True)
