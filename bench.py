@@ -669,7 +669,10 @@ def main():
                          "dense2sparse_distillation.sh:70-72); 16 x 2 per GPU = global batch 256 on 8 GPUs (config 3)")
     ap.add_argument("--no-zero2", action="store_true",
                     help="N>1: all-reduce + full optimizer on every rank instead of reduce-scatter / sharded AdamW / all-gather")
-    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient exchange (N>1)")
+    ap.add_argument("--grad-dtype", default="bf16", choices=["fp32", "bf16"],
+                    help="dtype of the gradient exchange at N > 1.  bf16 (default) is what the reference's bf16 DeepSpeed engine moves (SURVEY "
+                         "config 3: 4.07 GB per optimizer step); gradients ACCUMULATE in fp32 here either way (wgrad epilogues, master weights), "
+                         "only the exchanged copy is bf16.  fp32 doubles the xGMI bytes for an exact sum")
     ap.add_argument("--max-grad-norm", type=float, default=1.0, help="global-norm clipping (HF Trainer default 1.0); 0 = off")
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--ragged", action="store_true", help="SURVEY §8(d) ragged variant: text lengths U[600,1473], right-padded")
