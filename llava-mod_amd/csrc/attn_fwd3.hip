@@ -39,6 +39,12 @@
 #ifndef F3_ILV
 #define F3_ILV 1                   // 1: the VALU slice of half 0 between the step's two MFMAs, the slice of half 1 behind the second one
 #endif
+#ifndef F3_STAG
+#define F3_STAG 0                  // 1: the staggered schedule (halves half an iteration apart, one MFMA per fragment, three V buffers); 0: paired.
+                                   //    Measured (profiles/r05_attn_fwd3_staggered.jsonl, parity green): 528 / 600 / 813 / 791 TF against the paired
+                                   //    schedule's 600 / 708 / 907 / 951 — balancing the exponentials over the gaps does not repay reading every
+                                   //    K / V fragment twice; kept as the documented arm
+#endif
 #ifndef F3_RS2
 #define F3_RS2 1
 #endif
@@ -337,6 +343,163 @@ __device__ __forceinline__ void fwd3_block(const AttnP& p, char* smem, int qb, i
     }
   };
 
+#if F3_STAG
+  // ==================================================================================== staggered schedule (F3_STAG)
+  // The paired schedule above shares every K / V fragment between the halves, which makes both halves' scores ready at the same moment:
+  // all 64 exponentials of a tile then crowd into the 34 MFMA gaps between the row-max decision and the next tile's S^T MFMAs (two per gap:
+  // ~40 clocks of VALU issue in a 32-clock shadow) while the other 30 gaps stay empty, and with ONE wave on the SIMD nothing else fills
+  // either (profiles/r05_attn_ablation.md §3: the softmax costs 36-43 %).  Here the halves run HALF AN ITERATION APART:
+  //     block 1  S0^T(j)   = K(j) Q0^T          16 MFMAs   ||  half 1: exponentials of tile j-1, second part
+  //     block 2  O1^T     += V(j-1)^T P1(j-1)   16 MFMAs   ||  half 0: row maxima, decision, exponentials of tile j, first part
+  //     block 3  S1^T(j)   = K(j) Q1^T          16 MFMAs   ||  half 0: exponentials, second part
+  //     block 4  O0^T     += V(j)^T P0(j)       16 MFMAs   ||  half 1: row maxima, decision, exponentials of tile j, first part
+  // so at any moment exactly ONE half is exponentiating: ~1.2 exponentials per gap in 54 of the 64 gaps instead of 2 per gap in 34.  The
+  // price: a fragment feeds one MFMA again (the LDS read traffic of the 8-wave kernel), and V(j) is read in the iteration that also reads
+  // V(j-1): three V buffers (a tile is requested one iteration before its first read).
+  const bf16x8 zero8 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  (void)zero8;
+  float alpha_h[2] = {1.f, 1.f};
+  bool resc_h[2] = {false, false};
+  float pm2s[2] = {-INFINITY, -INFINITY}, pm3s[2] = {-INFINITY, -INFINITY};
+  auto decide_s = [&](auto hf_t) {
+    constexpr int HF = decltype(hf_t)::value;
+    float mx = fmaxf(fmaxf(pm0[HF], pm1[HF]), fmaxf(pm2s[HF], pm3s[HF]));
+    mx = f3_swap_max(mx);
+    resc_h[HF] = __builtin_amdgcn_ballot_w64((mx - mrun[HF]) * c > F3_THR) != 0;
+    const float mnew = resc_h[HF] ? fmaxf(mrun[HF], mx) : mrun[HF];
+    const float a0 = __builtin_amdgcn_exp2f((mrun[HF] - mnew) * c);
+    alpha_h[HF] = (mnew == mrun[HF]) ? 1.f : a0;
+    lrun[HF] = (lrun[HF] + rs[HF] + rs2[HF]) * alpha_h[HF];
+    rs[HF] = 0.f; rs2[HF] = 0.f;
+    mrun[HF] = mnew;
+    nmc[HF] = (mnew == -INFINITY) ? 0.f : -mnew * c;
+    F3_PIN(nmc[HF]);
+  };
+  // exp pair number pr (0..15) of half HF: key half pr >> 3, elements 2 (pr & 7), +1
+  auto exp_nr = [&](auto hf_t, const int pr) {
+    if (pr < 8) exp_pair(hf_t, KT0{}, 2 * pr); else exp_pair(hf_t, KT1{}, 2 * (pr - 8));
+  };
+  // VALU slices by gap (st = 0..15 inside a block).  HEAD: the block right after the half's S^T block; TAIL: the block after that.
+  auto valu_head = [&](auto masked_t, auto hf_t, const int st, const int mthr) {
+    constexpr int HF = decltype(hf_t)::value;
+    if (st == 2) { if (F3_ABL != 8) asm volatile("s_nop 7" ::: B2_CLOB_ALL); pm0[HF] = max8(masked_t, hf_t, KT0{}, 0, mthr); }
+    if (st == 3) pm1[HF] = max8(masked_t, hf_t, KT0{}, 8, mthr);
+    if (st == 4) pm2s[HF] = max8(masked_t, hf_t, KT1{}, 0, mthr);
+    if (st == 5) pm3s[HF] = max8(masked_t, hf_t, KT1{}, 8, mthr);
+    if (st == 6) decide_s(hf_t);
+    if (st == 7) exp_nr(hf_t, 0);
+    if (st == 8) exp_nr(hf_t, 1);
+    if (st == 10) exp_nr(hf_t, 2);
+    if (st == 11) exp_nr(hf_t, 3);
+    if (st == 13) exp_nr(hf_t, 4);
+    if (st == 14) exp_nr(hf_t, 5);
+    (void)HF;
+  };
+  auto valu_tail = [&](auto hf_t, const int st) {
+    // pairs 6..15 in gaps 0 1 3 4 6 7 9 10 12 13
+    const int q = st / 3, r = st % 3;
+    if (st <= 13 && r != 2) exp_nr(hf_t, 6 + 2 * q + r);
+  };
+  auto qk_block = [&](auto hf_t, const char* kb, auto&& valu) {
+    constexpr int HF = decltype(hf_t)::value;
+    bf16x8 kf[F3_DEPTH + 1];
+    auto kread = [&](const int st) { if (F3_ABL == 6) return pk[0][st & 3]; return *(const bf16x8*)(kb + kaddr[st & 7] + (st >> 3) * 8192); };
+#pragma unroll
+    for (int st = 0; st < F3_DEPTH; ++st) kf[st] = kread(st);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int kt = st >> 3, ks = st & 7, nx = st + F3_DEPTH;
+      if (nx < 16) kf[nx % (F3_DEPTH + 1)] = kread(nx);
+      if (F3_ABL == 4) { if (ks == 0) { for (int r = 0; r < 16; ++r) s[HF][kt][r] = (float)(r + kt); F3_PIN(s[HF][kt]); } }
+      else if (ks == 0) f3_qk<true>(HF * 8 + ks, s[HF][kt], kf[st % (F3_DEPTH + 1)]); else f3_qk<false>(HF * 8 + ks, s[HF][kt], kf[st % (F3_DEPTH + 1)]);
+      valu(st);
+      F3_SB();
+    }
+  };
+  auto pv_block = [&](auto hf_t, const char* vb, auto&& valu) {
+    constexpr int HF = decltype(hf_t)::value;
+    bf16x8 vf[F3_DEPTH + 1];
+    auto vread = [&](const int st) { if (F3_ABL == 6) return pk[1][st & 3]; return f3_lds_tr2(vb + vaddr[st & 3] + (st >> 2) * 4096); };
+#pragma unroll
+    for (int st = 0; st < F3_DEPTH; ++st) vf[st] = vread(st);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int kk = st >> 2, dt = st & 3, nx = st + F3_DEPTH;
+      if (nx < 16) vf[nx % (F3_DEPTH + 1)] = vread(nx);
+      if (F3_ABL == 3) { F3_PIN(vf[st % (F3_DEPTH + 1)]); } else f3_pv(4 * HF + dt, vf[st % (F3_DEPTH + 1)], pk[HF][kk]);
+      valu(st);
+      F3_SB();
+    }
+  };
+  auto valu_only = [&](auto&& valu) {                           // a block with no MFMAs to issue (drain): its VALU slices alone
+#pragma unroll
+    for (int st = 0; st < 16; ++st) { valu(st); F3_SB(); }
+  };
+  auto none = [&](const int) {};
+  auto dma_v3 = [&](const int t, const int slot) {
+    const uint32_t adv = (uint32_t)(t * 64 * p.ldv) * 2u, step = (uint32_t)(16 * p.ldv) * 2u;
+    char* dst = smem + 2 * F3_TB + slot * F3_TB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(dst + i * 4096), 16, vdo + adv + i * step, 0, 0, 0);
+  };
+
+  // ---- prologue: K(0), V(0) -> LDS
+  if (ntiles > 0) { dma_k(0, 0); dma_v3(0, 0); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int vs_prev = 2, vs_cur = 0, vs_next = 1;                      // ring slots of V(j-1), V(j), V(j+1)
+  for (int j = 0; j <= ntiles; ++j) {
+    if (F3_ABL != 5 && j + 1 < ntiles) { dma_k(j + 1, (j + 1) & 1); dma_v3(j + 1, vs_next); }
+    const bool do_q = (j < ntw), do_pv1 = (j >= 1 && j <= ntw);
+    const int mthr0 = (CAUSAL ? min(qrow[0], len - 1) : len - 1) - j * 64 - 4 * hi;
+    const int mthr1 = (CAUSAL ? min(qrow[1], len - 1) : len - 1) - j * 64 - 4 * hi;
+    const bool need_mask = (j * 64 + 64 > len) || (CAUSAL && j * 64 + 63 > qw0);
+    const char* kb = smem + (j & 1) * F3_TB;
+    const char* vprev = smem + 2 * F3_TB + vs_prev * F3_TB;
+    const char* vcur = smem + 2 * F3_TB + vs_cur * F3_TB;
+    using T = BoolTag<true>;
+    using F = BoolTag<false>;
+    // block 1: S0^T(j) || half 1's exponentials of tile j-1, second part
+    if (do_q) {
+      if (do_pv1) qk_block(H0{}, kb, [&](const int st) { valu_tail(H1{}, st); });
+      else qk_block(H0{}, kb, none);
+      asm volatile("" ::: "memory");
+    } else if (do_pv1) {
+      valu_only([&](const int st) { valu_tail(H1{}, st); });
+    }
+    // block 2: O1^T += V(j-1)^T P1(j-1) || half 0: maxima, decision, first exponentials of tile j
+    if (do_pv1) {
+      if (do_q) {
+        if (need_mask) pv_block(H1{}, vprev, [&](const int st) { valu_head(T{}, H0{}, st, mthr0); });
+        else pv_block(H1{}, vprev, [&](const int st) { valu_head(F{}, H0{}, st, mthr0); });
+      } else pv_block(H1{}, vprev, none);
+    } else if (do_q) {
+      if (need_mask) valu_only([&](const int st) { valu_head(T{}, H0{}, st, mthr0); });
+      else valu_only([&](const int st) { valu_head(F{}, H0{}, st, mthr0); });
+    }
+    if (do_q && resc_h[0]) {                                      // rare; no MFMA into half 0's strips is in flight (its last: block 4 of j-1)
+      asm volatile("s_nop 15\n\ts_nop 15" ::: B2_CLOB_ALL);
+      f3_scale_half<0>(alpha_h[0]);
+      resc_h[0] = false;
+    }
+    // block 3: S1^T(j) || half 0's exponentials, second part; block 4: O0^T += V(j)^T P0(j) || half 1: maxima, decision, first exponentials
+    if (do_q) {
+      qk_block(H1{}, kb, [&](const int st) { valu_tail(H0{}, st); });
+      if (need_mask) pv_block(H0{}, vcur, [&](const int st) { valu_head(T{}, H1{}, st, mthr1); });
+      else pv_block(H0{}, vcur, [&](const int st) { valu_head(F{}, H1{}, st, mthr1); });
+      if (resc_h[1]) {                                            // half 1's strips: last MFMA in block 2 of this iteration
+        asm volatile("s_nop 15\n\ts_nop 15" ::: B2_CLOB_ALL);
+        f3_scale_half<1>(alpha_h[1]);
+        resc_h[1] = false;
+      }
+    }
+    if (j == ntiles) break;
+    { const int t = vs_prev; vs_prev = vs_cur; vs_cur = vs_next; vs_next = t; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (F3_ABL != 1) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#else
   // ---- prologue: K(0) -> LDS
   if (ntiles > 0) dma_k(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -381,6 +544,7 @@ __device__ __forceinline__ void fwd3_block(const AttnP& p, char* smem, int qb, i
     asm volatile("" ::: "memory");
   }
 
+#endif
   // ---- epilogue: lane (query l31 of half hf, feature half hi) holds features dt*32 + hi*16 + r of its query
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: B2_CLOB_ALL);    // last asm MFMAs -> accumulator reads
   auto store_half = [&](auto hf_t) {
@@ -432,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd3_kernel(AttnP p) {
 
 void lmod_launch_attn_fwd3(const AttnP& p, int causal, hipStream_t stream) {
   static bool attr = false;
-  const int lds = 4 * F3_TB;
+  const int lds = (F3_STAG ? 5 : 4) * F3_TB;
   if (!__atomic_load_n(&attr, __ATOMIC_ACQUIRE)) {
     (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
