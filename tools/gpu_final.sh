@@ -7,8 +7,8 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/${1:-final}
 mkdir -p $OUT
-timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/bench -o a --output-format csv -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-teacher-prefetch > $OUT/bench_trace.log 2>&1)
+timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/bench -o a --output-format csv -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-teacher-prefetch > $OUT/bench_trace.log 2>&1)
 grep '^{' $OUT/bench_trace.log | tail -1 > $OUT/bench_line.json
 SQ1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 -d $OUT/gemm_sq -o a --output-format csv -- python $OLDPWD/tools/gemm_one.py > $OUT/gemm_sq.log 2>&1)
@@ -23,9 +23,9 @@ timeout 600 python tools/bench_kernels.py > $OUT/kernel_microbench.jsonl 2> $OUT
 timeout 300 python tools/bench_gemm.py > $OUT/gemm_shapes.json 2> $OUT/gemm_shapes.err
 timeout 300 python tools/bench_attn.py --bwd-only > $OUT/attn_bench.jsonl 2>/dev/null
 timeout 300 python tools/bench_attn.py >> $OUT/attn_bench.jsonl 2>/dev/null
-timeout 300 python tools/vendor_ab.py > $OUT/vendor_ab.jsonl 2>/dev/null
-timeout 1500 python bench.py --stage dpo --micro-batch 8 > $OUT/bench_dpo.json 2> $OUT/bench_dpo.err; echo "dpo rc=$?"
+if [ -n "$FINAL_DPO" ]; then timeout 1500 python bench.py --stage dpo --micro-batch 8 > $OUT/bench_dpo.json 2> $OUT/bench_dpo.err; echo "dpo rc=$?"; fi
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_form.json 2>/dev/null
-timeout 600 python bench.py --experts 8 --no-cpu-baseline > $OUT/bench_e8.json 2>/dev/null
+timeout 300 python tools/bench_r5_routing.py > $OUT/routing.jsonl 2>/dev/null
+timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
 (cd tools && timeout 300 python bench_attn.py --hd64 > $OUT/attn_hd64.jsonl 2>/dev/null; LMOD_ATTN_FWD=1 timeout 300 python bench_attn.py --hd64 > $OUT/attn_hd64_generic.jsonl 2>/dev/null)
 ls $OUT; tail -c 600 $OUT/bench_default.json

@@ -33,7 +33,7 @@ def stats_md():
     n_steps = steps_in_trace(qkv_calls, A) or (line["steps"] + line["warmup"])
     out = [f"# rocprofv3 --kernel-trace --stats of the default bench workload ({TAG})", "",
            "Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
-           "--no-cpu-baseline --no-teacher-prefetch` (teacher pipelining off so that kernel durations do not overlap; the "
+           "--no-cpu-baseline --no-extras --no-teacher-prefetch` (teacher pipelining off so that kernel durations do not overlap; the "
            "default bench line with pipelining on is in `*_bench_n1.json`).", "",
            f"{n_steps:g} optimizer steps in the trace ({line['warmup']} warm-up + {line['steps']} timed + the in-step-aggregate step; counted from the "
            f"{qkv_calls} fused QKV + RoPE launches = {LAYERS_QKV} layers x {A} micro-batches per step) of {A} micro-batches x "
@@ -199,3 +199,6 @@ if __name__ == "__main__":
     os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
     if os.path.exists(f"{src}/attn_bench.jsonl"):
         os.system(f"cp {src}/attn_bench.jsonl {dst}_attn_bench.jsonl")
+    for name in ("bench_driver_form.json", "routing.jsonl", "pytest_gpu.txt", "attn_hd64.jsonl"):
+        if os.path.exists(f"{src}/{name}"):
+            os.system(f"cp {src}/{name} {dst}_{name}")
