@@ -50,10 +50,10 @@ def stats_md():
     blocks = (gm // 256) * (12288 // 256)
     # (round 3: plain bf16 launches run on the 4-wave kernel, 256 threads per workgroup; older builds / LMOD_GEMM_WAVES=8: 512)
     rl = line["roofline"]
-    if any("gemm4_kernel<7, true>" in r["Kernel_Name"] for r in trace):
+    if any("gemm4_kernel<7, true" in r["Kernel_Name"] for r in trace):      # (round 5: a third template flag follows — `<7, true, false>`)
         # round 4: the teacher-QKV launch (24 rounds of the CUs) runs on the PERSISTENT instantiation, whose grid is one workgroup
         # per CU whatever the shape: the bench's own launches are told apart by their duration (+-12 % of the live figure)
-        dom = "gemm4_kernel<7, true>"
+        dom = "gemm4_kernel<7, true"
         # (with the persistent form taken from 4 rounds up several shapes of the step run on this instantiation with the same grid
         # and similar durations: the bench's own launches are the one place where the kernel is dispatched back to back, so they
         # are the LONGEST RUN of consecutive dispatches of it in start order)
@@ -75,7 +75,7 @@ def stats_md():
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
              if dom in r["Kernel_Name"] and int(r["Grid_Size_X"]) // tpw == blocks]
     out += ["", "## Dominant kernel cross-check", "",
-            f"`{dom}{'>' if dom.endswith('0') else ''}` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
+            f"`{dom}{'>' if dom.endswith('0') else ('...>' if dom.endswith('true') else '')}` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
             f"trace (the launches bench.py times with HIP events; the models' own QKV projections run on the fused QKV + RoPE instantiation), average {sum(d) / len(d):.1f} us, "
             f"min {min(d):.1f}, max {max(d):.1f}.  bench.py's live HIP-event figure in the same run: {rl['launch_ms'] * 1e3:.1f} us "
             f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak)."]
@@ -87,7 +87,7 @@ def stats_md():
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in trace:
         if "gemm4_kernel<7" in r["Kernel_Name"]:
-            kk = "persistent" if "true" in r["Kernel_Name"] else "one tile per workgroup"
+            kk = "persistent" if "gemm4_kernel<7, true" in r["Kernel_Name"] else "one tile per workgroup"
             agg[kk][0] += 1; agg[kk][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     if agg:
         ins = rl.get("in_step") or {}
