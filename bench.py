@@ -596,7 +596,7 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
-def exchange_object(dp, opt, steps, comm0=None):
+def exchange_object(dp, opt, steps, comm0=None, comm1=None):
     """What the data-parallel step exchanges: backend and world as torch.distributed reports them (so the line shows RCCL
     had N ranks), the static per-step plan of this rank, and — after a timed run — the collectives actually issued per step."""
     from llavamod import engine
@@ -604,14 +604,16 @@ def exchange_object(dp, opt, steps, comm0=None):
     ex = {"backend": ("rccl (torch 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()) if on else None,
           "world_seen_by_backend": dist.get_world_size() if on else 1,
           "zero2": bool(dp.zero2), "grad_dtype": "bf16" if dp.grad_dtype == torch.bfloat16 else "fp32",
-          "ep_size": dp.ep_size, "overlap": "spans exchanged from wgrad-ready hooks on RCCL's own high-priority stream"}
+          "ep_size": dp.ep_size, "overlap": "spans exchanged from wgrad-ready hooks on RCCL's own high-priority stream",
+          "collectives": ("C-ABI (csrc/comm.hip: lmod_reduce_scatter_grads / lmod_allreduce_grads / lmod_allgather_params / lmod_moe_all_to_all, own RCCL "
+                          "communicator, side stream)") if getattr(dp, "native", False) else "torch.distributed"}
     if dp.enabled:
         ex["plan"] = dp.exchange_plan()
     if steps and dp.enabled:
         base = comm0 or {}
         ex["issued_per_step"] = {k: {"calls": round((v[0] - base.get(k, [0, 0])[0]) / steps, 2),
                                      "bytes": int((v[1] - base.get(k, [0, 0])[1]) / steps)}
-                                 for k, v in sorted(engine.COMM.items())}
+                                 for k, v in sorted((comm1 if comm1 is not None else engine.COMM).items())}
     return ex
 
 
@@ -823,6 +825,7 @@ def main():
         step(i)
     comm0 = {k: list(v) for k, v in engine.COMM.items()}
     dt, last = timed(step, 0, args.steps, first=args.warmup)
+    comm1 = {k: list(v) for k, v in engine.COMM.items()}      # the collectives of the TIMED steps only (later legs issue more)
     loss_val = float(last)
 
     if rank == 0:
@@ -891,7 +894,7 @@ def main():
                          "in_step": in_step,
                          "whole_step": whole_step_object(sps / world, args.stage, args.experts)},
             "optimizer_ms": optimizer_ms,
-            "exchange": exchange_object(dp, opt, args.steps, comm0),
+            "exchange": exchange_object(dp, opt, args.steps, comm0, comm1),
         }
         want_extras = (world == 1 and not args.no_extras and args.stage == "mimic" and args.experts == 4 and not args.ragged
                        and B == 16 and args.ep == 1)
