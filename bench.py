@@ -828,29 +828,35 @@ def main():
     comm1 = {k: list(v) for k, v in engine.COMM.items()}      # the collectives of the TIMED steps only (later legs issue more)
     loss_val = float(last)
 
+    # Everything below that LAUNCHES work runs on EVERY rank: the in-step aggregate is one more optimizer step and the optimizer timing
+    # runs the sharded AdamW with its all-gathers — at N > 1 both contain collectives, and a rank that ran them alone would wait for its
+    # peers forever (rounds 4's bench did exactly that on rank 0; the N > 1 lines of round 3 predate it).  Only rank 0 reports.
+    # dominant kernel (the plain bf16 NT GEMM: gemm4_kernel<7>, ~28 % of GPU time in profiles/) at the shape it spends most time on —
+    # the teacher's fused QKV projection — measured live with HIP events on the launch stream (torch's current stream)
+    gm, gn, gk = B * 2048, 12288, 4096
+    a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
+    w = torch.randn(gn, gk, device=dev).to(torch.bfloat16)
+    o = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        K.gemm_nt(a, w, out=o)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        K.gemm_nt(a, w, out=o)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / 10
+    gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
+    del a, w, o
+    in_step = in_step_gemm_aggregate(step, args.warmup + args.steps)
+    optimizer_ms = time_optimizer(gb, opt, world * A)
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         sps = args.steps * B * A * world / dt
         ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
         achieved = ledger * sps / world
-        # dominant kernel (the plain bf16 NT GEMM: gemm4_kernel<7>, ~28 % of GPU time in profiles/) at the shape it spends most time on —
-        # the teacher's fused QKV projection — measured live with HIP events on the launch stream (torch's current stream)
-        gm, gn, gk = B * 2048, 12288, 4096
-        a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
-        w = torch.randn(gn, gk, device=dev).to(torch.bfloat16)
-        o = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
-        for _ in range(2):
-            K.gemm_nt(a, w, out=o)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            K.gemm_nt(a, w, out=o)
-        e1.record()
-        torch.cuda.synchronize()
-        gemm_ms = e0.elapsed_time(e1) / 10
-        gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
-        del a, w, o
-        in_step = in_step_gemm_aggregate(step, args.warmup + args.steps)
-        optimizer_ms = time_optimizer(gb, opt, world * A)
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live); the
         # ALGORITHMIC bytes are computed here from the shape this function launches: A + B + C once, bf16
         algo_bytes = gemm_algorithmic_bytes(gm, gn, gk)

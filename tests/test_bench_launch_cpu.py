@@ -100,3 +100,16 @@ def test_bench_self_launch_world8_config3_and_config5():
     assert plan["sharded_params"] + plan["replicated_params"] + plan["rank_local_params"] == out["trainable_params"]
     assert out["optimizer_state_elems_rank0"] == plan["sharded_params"] // 8 + plan["replicated_params"] + one_expert_per_layer
     assert plan["collectives_per_step"]["reduce_scatter"]["calls"] == 12 * 2 + 2        # dense FFN pairs + projector; experts stay local
+
+
+def test_every_rank_runs_what_contains_collectives():
+    """Round 4's bench ran its in-step aggregate (one more optimizer step) and the optimizer timing (sharded AdamW + all-gathers) inside
+    `if rank == 0:` — at N > 1 rank 0 then waits for peers that never come.  Everything that launches work must sit in front of that block."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    gate = main.index("    if rank == 0:\n        sps = ")
+    for call in ("in_step_gemm_aggregate(step", "time_optimizer(gb, opt", "K.gemm_nt(a, w, out=o)"):
+        assert 0 < main.index(call) < gate, call
+    tail = main[gate:]
+    for call in ("in_step_gemm_aggregate(", "time_optimizer(", "timed(step,"):
+        assert call not in tail.split("want_extras")[0], call          # (the world-1-only extra legs come after `want_extras`)
