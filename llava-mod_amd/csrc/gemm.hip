@@ -2325,6 +2325,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Host-checked: M % 8 == 0, N % 8 == 0, lda / ldb % 8 == 0, 16-byte aligned operands, every operand window below 2 GiB.
 // =============================================================================================
 #include "gemm4t_loop_asm.h"
+#ifndef G4T_OB
+#define G4T_OB 0                    // 1: the one-barrier schedule of round 5 (tools/gen_gemm4t_loop.py --variant ob): reads at 2 per 3 MFMAs, barrier at MFMA 56
+#endif
+#if G4T_OB
+#include "gemm4t_loop_asm_ob.h"
+#endif
 #define G4T_SUB 8448
 #define G4T_PIECE 1056
 #define G4T_OPB 33792
@@ -2436,7 +2442,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(remB > 2ull * ksB ? remB - 2u * ksB : 0u)), 0x00020000u};
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // K tile 0 landed (tile 1's 16 pieces may still fly)
     asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#if G4T_OB
+    G4T_ASM_LOOP_OB();
+#else
     G4T_ASM_LOOP();
+#endif
     // the asm MFMAs are invisible to the hazard recognizer: let the last accumulator writes retire before reading them
     asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
   }

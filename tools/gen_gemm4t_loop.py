@@ -25,6 +25,9 @@ import argparse
 import os
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--variant", default="b2", help="b2: round 4's schedule (fragment reads one per MFMA in two bursts, barriers at 38 and 86); "
+                                                "ob: ONE barrier per K tile (at MFMA 56) and the 64 transposing reads at two per three MFMAs — the LDS "
+                                                "runs at 2/3 of its 128 B/clk in the read windows instead of at all of it")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd", "csrc",
                                               "gemm4t_loop_asm.h"))
 args = ap.parse_args()
@@ -65,22 +68,52 @@ def place(start, instrs, cap=2):          # in order, into the gaps from `start`
     return i
 
 
-# k-step 0: this tile's k-step-1 fragments (stage of tile t: register set 1), one read per MFMA (four waves x 512 bytes per 16 cycles is
-# the LDS's whole 128 bytes per clock)
-for n in range(32):
-    sched[n].append(rd(n, 1, 1))
-place(32, ["v_sub_u32 %[ra1], %[sa], %[ra1]", "v_sub_u32 %[rb1], %[sb], %[rb1]"], cap=1)
-sched[38] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]                      # every wave holds all of tile t: its stage is free
-at = [39, 44, 49, 54, 59, 64, 69, 74, 79, 84] + [89, 94, 99, 104, 109, 114]
-for pc, a in enumerate(at):
-    piece(a, pc)
-n_before = sum(1 for a in at if a <= 86)
-sched[86] += [f"s_waitcnt vmcnt({n_before})", "s_barrier"]             # all of tile t+1 has landed, for everyone
-for n in range(32):                                                     # tile t+1's k-step-0 fragments (register set 0)
-    assert len(sched[87 + n]) <= 1
-    sched[87 + n].append(rd(n, 0, 0))
-tail = ["v_sub_u32 %[ra0], %[sa], %[ra0]", "v_sub_u32 %[rb0], %[sb], %[rb0]"]
-end = place(119, tail)
+if args.variant == "ob":
+    # B fragments first (all eight are needed by the first eight MFMAs of k-step 1), then A (fragment mt is needed at MFMA 64 + 8 mt)
+    order1 = list(range(16, 32)) + list(range(0, 16))
+    slots = [i for i in range(0, 48) if i % 3 != 2]
+    assert len(slots) == 32
+    for n, i in zip(order1, slots):
+        sched[i].append(rd(n, 1, 1))
+    place(48, ["v_sub_u32 %[ra1], %[sa], %[ra1]", "v_sub_u32 %[rb1], %[sb], %[rb1]"], cap=1)
+    # ONE barrier: my reads of tile t are done (the last one was issued 9 MFMAs ago), all my pieces of tile t+1 (issued one tile ago)
+    # have landed => for everyone: stage t is free, tile t+1 is complete
+    sched[56] += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    at = [58 + 4 * k for k in range(16)]                                  # 58 .. 118
+    for pc, a in enumerate(at):
+        piece(a, pc)
+    # tile t+1's k-step-0 fragments (register set 0): A first (MFMA i of the next tile's k-step 0 needs A fragment i >> 3 and B fragment i & 7,
+    # i.e. all of B within the first eight) — so B first here too, A behind
+    order0 = list(range(16, 32)) + list(range(0, 16))
+    slots0 = [i for i in range(59, 128) if len(sched[i]) == 0 and len(sched[i + 1] if i + 1 < 128 else []) < 2][:]
+    k = 0
+    for i in range(59, 122):
+        if k == 32:
+            break
+        if len(sched[i]) >= 1:
+            continue
+        sched[i].append(rd(order0[k], 0, 0))
+        k += 1
+    assert k == 32, k
+    tail = ["v_sub_u32 %[ra0], %[sa], %[ra0]", "v_sub_u32 %[rb0], %[sb], %[rb0]"]
+    end = place(max(i for i in range(128) if any("%[ra0]" in x or "%[rb0]" in x for x in sched[i])) + 1, tail)
+else:
+    # k-step 0: this tile's k-step-1 fragments (stage of tile t: register set 1), one read per MFMA (four waves x 512 bytes per 16 cycles is
+    # the LDS's whole 128 bytes per clock)
+    for n in range(32):
+        sched[n].append(rd(n, 1, 1))
+    place(32, ["v_sub_u32 %[ra1], %[sa], %[ra1]", "v_sub_u32 %[rb1], %[sb], %[rb1]"], cap=1)
+    sched[38] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]                      # every wave holds all of tile t: its stage is free
+    at = [39, 44, 49, 54, 59, 64, 69, 74, 79, 84] + [89, 94, 99, 104, 109, 114]
+    for pc, a in enumerate(at):
+        piece(a, pc)
+    n_before = sum(1 for a in at if a <= 86)
+    sched[86] += [f"s_waitcnt vmcnt({n_before})", "s_barrier"]             # all of tile t+1 has landed, for everyone
+    for n in range(32):                                                     # tile t+1's k-step-0 fragments (register set 0)
+        assert len(sched[87 + n]) <= 1
+        sched[87 + n].append(rd(n, 0, 0))
+    tail = ["v_sub_u32 %[ra0], %[sa], %[ra0]", "v_sub_u32 %[rb0], %[sb], %[rb0]"]
+    end = place(119, tail)
 # descriptors and the LDS-DMA base move on to K tile t+3 (after this tile's last piece)
 walk = ["s_sub_u32 %[dma], %[dsum], %[dma]",
         "s_add_u32 s84, s84, %[ksA]", "s_addc_u32 s85, s85, 0", "s_sub_u32 s86, s86, %[ksA]", "s_cselect_b32 s86, 0, s86",
@@ -131,6 +164,7 @@ for i in range(4):
     ins.append(f'[dB{i}] "s"(g4_dB[{i}])')
 clob = ['"memory"', '"scc"'] + [f'"s{i}"' for i in range(84, 92)] + [f'"v{i}"' for i in range(128, 256)]
 body = lines[n_head:]
+body = lines[n_head:]
 n_dma = sum(1 for l in body if "buffer_load" in l)
 n_rd = sum(1 for l in body if "ds_read" in l)
 n_mf = sum(1 for l in body if "v_mfma" in l)
@@ -139,7 +173,7 @@ H = ["// GENERATED by tools/gen_gemm4t_loop.py — do not edit.",
      "// The K loop of gemm4t_kernel (C += A^T B, both operands reduction-major) as one inline-asm statement.", "#pragma once",
      f"// G4T_ASM_LOOP: per K tile {n_mf} MFMAs, {n_rd} ds_read_b64_tr_b16, {n_dma} LDS-DMA pieces, 2 barriers, "
      f"{len(body) - n_mf - n_rd - n_dma - 2} other instructions",
-     "#define G4T_ASM_LOOP() asm volatile( \\"]
+     f"#define G4T_ASM_LOOP{'_OB' if args.variant == 'ob' else ''}() asm volatile( \\"]
 for l in lines:
     H.append(f'    "{l}\\n\\t" \\')
 H.append("    : " + ", ".join(outs) + " \\")
