@@ -1479,6 +1479,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     T.rowsA = rowsA; T.rowsB = rowsB;
     const int Kv8 = (Kv + 7) & ~7;
     T.bytesA = Kv > 0 ? (uint32_t)(((long long)(rowsA - 1) * p.lda + Kv8) * 2) : 0u;
+    // (MODE 1: the window spans the gate rows AND the up rows, p.N weight rows apart.  In the persistent forms a ragged N edge is cut by
+    // this byte count alone — the per-lane offsets there do not depend on the tile — so gate-side rows between rowsB and the tile's 128
+    // read LIVE weight rows (the up rows' window covers them); the epilogue masks those columns (`cs >= p.N`), nothing of them is stored)
     T.bytesB = Kv > 0 ? (uint32_t)(((long long)((MODE == 1 ? p.N : 0) + rowsB - 1) * p.ldb + Kv8) * 2) : 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
