@@ -368,6 +368,11 @@ def check_trainer_fns(R):
     check("get_p", olosses.get_p(t_logits), p); check("get_logp", olosses.get_logp(s_logits), lp)
     ra = R.at.AlignTrainer.compute_align_loss(me, lp, p, labels)
     check("compute_align_loss", olosses.compute_align_loss(lp, p, labels), ra)
+    # `--distill_all_tokens True` (config/args.py:110; align_trainer.py:516-520): the mask is all ones, ignored / padding rows included
+    me_all = SimpleNamespace(args=SimpleNamespace(moe_enable=True, distill_all_tokens=True), moe_loss_enable=True, label_pad_token_id=-100)
+    ra_all = R.at.AlignTrainer.compute_align_loss(me_all, lp, p, labels)
+    check("compute_align_loss (distill_all_tokens)", olosses.compute_align_loss(lp, p, labels, distill_all_tokens=True), ra_all)
+    assert abs(float(ra_all) - float(ra)) > 1e-6, "the all-tokens mask must change the loss on a batch with ignored rows"
     md = SimpleNamespace(args=SimpleNamespace(moe_enable=True), moe_loss_enable=True, label_pad_token_id=-100, beta=0.1,
                          label_smoothing=0.0, loss_type="sigmoid")
     small = torch.randn(2, 6, 512, generator=g)
