@@ -1,9 +1,9 @@
 // Flash attention forward for head dim 128 on gfx950, ONE WAVE PER SIMD (round 5) — the decoder's attention core
 // (qwen2/modeling_qwen2.py:700-708 SDPA path, :290-309 eager path; causal + right-padding key mask, GQA).
 //
-// attn_fwd2.hip runs 8 waves of 32 queries: every wave reads the whole 64-key K and V tile from LDS for 32 MFMAs, i.e. 256 KiB of LDS
-// reads per tile and CU = 2048 clocks of the LDS's 128 bytes per clock beside 2048 MFMA clocks per SIMD — the two pipes are co-saturated,
-// and the timing ablations (profiles/r05_attn_ablation.md) show the kernel paying for both.  Here a workgroup is 4 waves = one wave per
+// attn_fwd2.hip runs 8 waves of 32 queries: every wave reads the whole 64-key K and V tile from LDS for 32 MFMAs — 48 read instructions
+// and their waits per wave and tile, which the timing ablations (profiles/r05_attn_ablation.md) price at 10-16 % of the kernel (the LDS array
+// itself, 256 B/clk for these reads, is ~20 % busy).  Here a workgroup is 4 waves = one wave per
 // SIMD with the whole 512-register file, a wave owns 64 queries as TWO independent 32-query halves, and every K / V fragment read
 // from LDS feeds two MFMAs (one per half): half the LDS traffic per flop, no second wave competing for the SIMD's VALU issue, and
 // the softmax of one half is independent work beside the MFMAs of the other.

@@ -26,8 +26,8 @@ import os
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", default="b2", help="b2: round 4's schedule (fragment reads one per MFMA in two bursts, barriers at 38 and 86); "
-                                                "ob: ONE barrier per K tile (at MFMA 56) and the 64 transposing reads at two per three MFMAs — the LDS "
-                                                "runs at 2/3 of its 128 B/clk in the read windows instead of at all of it")
+                                                "ob: ONE barrier per K tile (at MFMA 56) and the 64 transposing reads at two per three MFMAs instead of one per "
+                                                "MFMA in two bursts (measured -3 ... -4 %: the bursts are not the limiter)")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd", "csrc",
                                               "gemm4t_loop_asm.h"))
 args = ap.parse_args()
@@ -98,8 +98,8 @@ if args.variant == "ob":
     tail = ["v_sub_u32 %[ra0], %[sa], %[ra0]", "v_sub_u32 %[rb0], %[sb], %[rb0]"]
     end = place(max(i for i in range(128) if any("%[ra0]" in x or "%[rb0]" in x for x in sched[i])) + 1, tail)
 else:
-    # k-step 0: this tile's k-step-1 fragments (stage of tile t: register set 1), one read per MFMA (four waves x 512 bytes per 16 cycles is
-    # the LDS's whole 128 bytes per clock)
+    # k-step 0: this tile's k-step-1 fragments (stage of tile t: register set 1), one read per MFMA (four waves x 512 bytes per 16 cycles =
+    # 128 of the 256 bytes per clock this read moves: half the LDS array's rate)
     for n in range(32):
         sched[n].append(rd(n, 1, 1))
     place(32, ["v_sub_u32 %[ra1], %[sa], %[ra1]", "v_sub_u32 %[rb1], %[sb], %[rb1]"], cap=1)
