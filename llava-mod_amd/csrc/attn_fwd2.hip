@@ -56,6 +56,9 @@ __device__ unsigned long long f2_trace_buf[8 * 128];
 #endif                              //    FMAs / adds).  Measured round 4: 752 -> 505 TF (B16 S2048 causal) — the even-aligned register pairs cost
 #if 0                               //    hipcc 34-39 spilled VGPRs and compiler moves through a[0:63] (the ISA audit in tests/test_abi.py fails)
 #endif
+#ifndef F2_INPIN
+#define F2_INPIN 0                  // 1: a VALU slice's input is pinned behind the MFMA it follows in the source (see attn_fwd3.hip F3_INPIN)
+#endif
 #ifndef F2_DMA
 #define F2_DMA 1                    // round 5: K / V tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction): no
 #endif                              //   staging registers, no ds_write issue slots, no in-loop wait on a register load (0: the round-2 path —
@@ -412,6 +415,7 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
   // exp2 of 2 scores of key half KT (elements e0, e0+1 of s[KT]) against nmc; packs a finished group of 8 into pk[2*KT + g]
   auto exp_pair = [&](auto kt_t, const int e0) {
     constexpr int KT = decltype(kt_t)::value;
+    if (F2_INPIN) F2_PIN(s[KT]);
 #if F2_PK
     {   // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of work per issue slot): the scale-and-shift of both scores in
         // one instruction, the row sum as two partials (rs2) in one
