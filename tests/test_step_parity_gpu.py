@@ -590,6 +590,57 @@ def test_seeded_mid_dpo_step_vs_oracle(loss_type):
         assert e <= max(2.0 * floor, 1e-2), (n, e, floor)
 
 
+def _token_logps(logits, labels):
+    """log p(label) at every labelled, shifted position of every sample (dpo_trainer.py:483-495 before the sum): fp32 [n]."""
+    lb = labels[:, 1:]
+    keep = lb != IGNORE_INDEX
+    lg = logits[:, :-1].float().log_softmax(-1)
+    return torch.gather(lg, 2, lb.clamp_min(0).unsqueeze(2).to(lg.device)).squeeze(2)[keep.to(lg.device)].detach().cpu()
+
+
+def test_per_token_logp_error_is_at_the_bf16_floor():
+    """The preference stage's scalars are sigmoids of differences of SUMS of per-token log-probabilities, so one sample of them says
+    little about a kernel's accuracy (bench.py --stage dpo prints why).  The testable statistic is the per-token error itself: root mean
+    square of log p(label) against the fp32 oracle over every labelled token of a 2 x 160-token batch, for the dense teacher (no
+    routing) and for the MoE student (oracle routed with the product's own picks), held to 1.5x the same statistic of the oracle's
+    bf16 twin — the reference's own bf16 arithmetic."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    vc, sc, tc = _mid_cfgs()
+    o_student, o_teacher = _seeded_pair(17, sc, tc, vc)
+    batch = _mid_batch(33, 2, 160, sc.vocab_size, vc.image_size, True)
+    student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
+    picks = {}
+    for li, m in enumerate(student.moe_layers()):
+        m.deterministic = True
+        picks[li] = []
+        m.register_forward_hook(lambda mod, a, o, li=li: picks[li].append((mod.last_state.idx1.cpu(), mod.last_state.idx2.cpu())))
+    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+    bb = _bf16_batch(batch)
+    student.train(); teacher.eval()
+    with torch.no_grad():
+        hs, ht = student(**hb), teacher(**hb)
+    o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
+    tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
+    tw_s.train(); tw_t.eval(); tw_s.set_gate_noise([None, None])
+    for li, (om, ot) in enumerate(zip(_oracle_moes(o_student), _oracle_moes(tw_s))):
+        om.forced = list(picks[li]); ot.forced = list(picks[li])
+    with torch.no_grad():
+        os_, ot_ = o_student(**batch), o_teacher(**batch)
+        ts_, tt_ = tw_s(**bb), tw_t(**bb)
+    for name, prod, ref, twin in (("teacher", ht, ot_, tt_), ("student", hs, os_, ts_)):
+        assert torch.equal(prod.labels.cpu(), ref.labels)
+        r = _token_logps(ref.logits, ref.labels)
+        e_prod = (_token_logps(prod.logits, ref.labels) - r).double()
+        e_twin = (_token_logps(twin.logits, ref.labels) - r).double()
+        rms_p, rms_t = float(e_prod.pow(2).mean().sqrt()), float(e_twin.pow(2).mean().sqrt())
+        n = e_prod.numel()
+        print(f"{name}: {n} labelled tokens, per-token log-prob RMS error: product {rms_p:.5f}, bf16 twin {rms_t:.5f}; "
+              f"bias product {float(e_prod.mean()):+.5f}, twin {float(e_twin.mean()):+.5f}")
+        assert n >= 120 and rms_p <= 1.5 * rms_t + 1e-4, (name, rms_p, rms_t)
+        # and no systematic offset beyond what the spread allows: |mean| within 4 standard errors of the twin's spread
+        assert abs(float(e_prod.mean())) <= 4.0 * rms_t / n ** 0.5 + 1e-4, (name, float(e_prod.mean()), rms_t, n)
+
+
 def test_materialising_api_matches_oracle():
     """get_p / get_logp / compute_align_loss on materialised tensors (slow-path API parity)."""
     from llavamod.train.align_trainer import AlignTrainer
