@@ -690,6 +690,14 @@ static bool bwd_generic() {      // LMOD_ATTN_BWD=1: hd-128 backward through the
   return v;
 }
 
+#ifndef LMOD_ATTN_BWD64_DEFAULT
+#define LMOD_ATTN_BWD64_DEFAULT 2
+#endif
+static bool bwd64_fast() {       // LMOD_ATTN_BWD64=1: hd-64 backward through the generic kernels; 2: the one-wave-per-SIMD kernels
+  static const bool v = [] { const char* e = getenv("LMOD_ATTN_BWD64"); return (e && e[0] ? atoi(e) : LMOD_ATTN_BWD64_DEFAULT) != 1; }();
+  return v;
+}
+
 static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
                          int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
@@ -714,8 +722,8 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo, cu_seqlens);
-  if (hd == 128 && !bwd_generic()) {
-    lmod_launch_attn_bwd2(p, causal, stream);
+  if ((hd == 128 || (hd == 64 && bwd64_fast())) && !bwd_generic()) {
+    lmod_launch_attn_bwd2(p, causal, stream, hd);
     return lmod_launch_status();
   }
   constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;

@@ -103,8 +103,13 @@ __device__ __forceinline__ void hazard_pad(f32x16& a, f32x16& b) {
 }
 __device__ __forceinline__ void hazard_pad(f32x16& a) { asm volatile("s_nop 3" : "+v"(a)::B2_CLOB_ALL); }
 
-template <bool DKV, bool CAUSAL>
+template <bool DKV, bool CAUSAL, int HD>
 __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, int ho, int b) {
+  // Head dim 64 keeps the tile images (pitches, swizzle, owner strips) and the phase order and drops what belongs to the absent upper
+  // feature half: KS reduction steps in S / dP, DT 32-feature strips per accumulator group, CH 16-byte chunks per staged row.  The
+  // softmax arithmetic per tile is the same, so VP of its two-element pieces go behind every MFMA instead of one.
+  constexpr int KS = HD / 16, DT = HD / 32, NST = 2 * DT, CH = HD / 8, CHS = HD == 128 ? 4 : 3, VP = 128 / HD, NLD = HD / 64;
+  static_assert(HD == 128 || HD == 64, "head dim 64 or 128");
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -117,22 +122,22 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   const float c = p.scale * 1.4426950408889634f;
   const int gsz = DKV ? p.group : 1;
 
-  const bf16_t* Xo = DKV ? p.K + tok0 * p.ldk + ho * 128 : p.Q + tok0 * p.ldq + ho * 128;
-  const bf16_t* Yo = DKV ? p.V + tok0 * p.ldv + ho * 128 : p.dO + tok0 * p.lddo + ho * 128;
+  const bf16_t* Xo = DKV ? p.K + tok0 * p.ldk + ho * HD : p.Q + tok0 * p.ldq + ho * HD;
+  const bf16_t* Yo = DKV ? p.V + tok0 * p.ldv + ho * HD : p.dO + tok0 * p.lddo + ho * HD;
   const int ldxo = DKV ? p.ldk : p.ldq, ldyo = DKV ? p.ldv : p.lddo;
-  const bf16_t* Xs = DKV ? p.Q + tok0 * p.ldq + (ho * p.group) * 128 : p.K + tok0 * p.ldk + (ho / p.group) * 128;
-  const bf16_t* Ys = DKV ? p.dO + tok0 * p.lddo + (ho * p.group) * 128 : p.V + tok0 * p.ldv + (ho / p.group) * 128;
+  const bf16_t* Xs = DKV ? p.Q + tok0 * p.ldq + (ho * p.group) * HD : p.K + tok0 * p.ldk + (ho / p.group) * HD;
+  const bf16_t* Ys = DKV ? p.dO + tok0 * p.lddo + (ho * p.group) * HD : p.V + tok0 * p.ldv + (ho / p.group) * HD;
   const int ldxs = DKV ? p.ldq : p.ldk, ldys = DKV ? p.lddo : p.ldv;
 
   // ---- owner fragments X (B operands of S): row ow0 + 32*os + l31, features ks*16 + hi*8 .. +7
-  bf16x8 xf[2][8];
+  bf16x8 xf[2][KS];
   float olse[2] = {0.f, 0.f}, odl[2] = {0.f, 0.f};             // dQ kernel: the lane's own rows' lse (log2 units) and delta
 #pragma unroll
   for (int os = 0; os < 2; ++os) {
     const int row = ow0 + os * 32 + l31;
     const bf16_t* xp = Xo + (long long)min(row, S - 1) * ldxo + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       xf[os][ks] = *(const bf16x8*)(xp + ks * 16);
       if (row >= S) xf[os][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -144,16 +149,16 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   }
   // ---- owner image Y: rows o0 .. o0+255 (zeros past the end of the sequence) -> LDS, 272-byte rows
   {
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yo, 0, (int)(((long long)(S - 1) * ldyo + 128) * 2), 0x00020000);
-    u32x4 v[16];                                                 // all 16 loads in flight (the main loop's registers are not live yet)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yo, 0, (int)(((long long)(S - 1) * ldyo + HD) * 2), 0x00020000);
+    u32x4 v[CH];                                                 // all loads in flight (the main loop's registers are not live yet)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + 256 * i, row = id >> CHS, ch = id & (CH - 1);
       v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (uint32_t)((o0 + row) * ldyo + ch * 8) * 2u, 0, 0));
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + 256 * i, row = id >> CHS, ch = id & (CH - 1);
       *(u32x4*)(smem + row * B2_YPITCH + ch * 16) = v[i];
     }
   }
@@ -166,9 +171,9 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   int total = per_head * gsz;
   if (DKV && o0 >= len) total = 0;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xs, 0, (int)(((long long)(S - 1) * ldxs + gsz * 128) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rys = __builtin_amdgcn_make_buffer_rsrc((void*)Ys, 0, (int)(((long long)(S - 1) * ldys + gsz * 128) * 2), 0x00020000);
-  const int srow = tid >> 4, sch = tid & 15;                    // staging: rows srow and srow + 16, chunk sch
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xs, 0, (int)(((long long)(S - 1) * ldxs + gsz * HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rys = __builtin_amdgcn_make_buffer_rsrc((void*)Ys, 0, (int)(((long long)(S - 1) * ldys + gsz * HD) * 2), 0x00020000);
+  const int srow = tid >> CHS, sch = tid & (CH - 1);                    // staging: chunk sch of rows srow (hd 128: and srow + 16)
   const uint32_t xg0 = (uint32_t)(srow * ldxs + sch * 8) * 2u, xg1 = xg0 + (uint32_t)(16 * ldxs) * 2u;
   const uint32_t yg0 = (uint32_t)(srow * ldys + sch * 8) * 2u, yg1 = yg0 + (uint32_t)(16 * ldys) * 2u;
   const int wa0 = B2_YIMG + srow * B2_PITCH + ((sch ^ ((srow >> 3) & 3)) << 4);
@@ -182,11 +187,11 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   auto gload = [&](const int) {
     const int hh = ghh, j = gj;
     if (++gj == nt) { gj = first; ++ghh; }
-    const uint32_t ax = (uint32_t)(j * 32 * ldxs + hh * 128) * 2u, ay = (uint32_t)(j * 32 * ldys + hh * 128) * 2u;
+    const uint32_t ax = (uint32_t)(j * 32 * ldxs + hh * HD) * 2u, ay = (uint32_t)(j * 32 * ldys + hh * HD) * 2u;
     xr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg0 + ax, 0, 0));
-    xr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg1 + ax, 0, 0));
+    if constexpr (NLD == 2) xr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg1 + ax, 0, 0));
     yr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg0 + ay, 0, 0));
-    yr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg1 + ay, 0, 0));
+    if constexpr (NLD == 2) yr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rys, yg1 + ay, 0, 0));
     if constexpr (DKV) {        // lse / delta of the tile's 32 rows: lanes 0-31 of every wave fetch them (no branch, no arithmetic
       const int t = j * 32 + l31;      // on the loaded value here: either would make hipcc wait for the loads at once)
       const uint32_t o = (hi == 0 && t < S) ? (uint32_t)((hh * p.S + t) * 4) : 0xffffffffu;
@@ -197,9 +202,9 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   auto lwrite = [&](const int buf) {
     char* bb = smem + buf * B2_BUF;
     *(u32x4*)(bb + wa0) = xr0;
-    *(u32x4*)(bb + wa1) = xr1;
+    if constexpr (NLD == 2) *(u32x4*)(bb + wa1) = xr1;
     *(u32x4*)(bb + B2_TILE + wa0) = yr0;
-    *(u32x4*)(bb + B2_TILE + wa1) = yr1;
+    if constexpr (NLD == 2) *(u32x4*)(bb + B2_TILE + wa1) = yr1;
     if constexpr (DKV) {
       if (tid < 32) {
         *(float*)(bb + B2_YIMG + B2_LD + tid * 4) = __uint_as_float(lsr) * 1.4426950408889634f;
@@ -221,11 +226,11 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   int lda = B2_YIMG + B2_LD + hi * 16;
   const int ya = (wave * 64 + l31) * B2_YPITCH + hi * 16;
 
-  auto rd_xs = [&](const int ks) { if (B2_ABL & 8) return xf[0][ks]; return *(const bf16x8*)(smem + rowa[ks & 1] + (ks >> 1) * 64); };
-  auto rd_ys = [&](const int ks) { if (B2_ABL & 8) return xf[1][ks]; return *(const bf16x8*)(smem + rowa[ks & 1] + B2_TILE + (ks >> 1) * 64); };
-  auto rd_y = [&](const int os, const int ks) { if (B2_ABL & 8) return xf[os][ks]; return *(const bf16x8*)(smem + ya + os * 32 * B2_YPITCH + ks * 32); };
+  auto rd_xs = [&](const int ks) { if (B2_ABL & 8) return xf[0][ks % KS]; return *(const bf16x8*)(smem + rowa[ks & 1] + (ks >> 1) * 64); };
+  auto rd_ys = [&](const int ks) { if (B2_ABL & 8) return xf[1][ks % KS]; return *(const bf16x8*)(smem + rowa[ks & 1] + B2_TILE + (ks >> 1) * 64); };
+  auto rd_y = [&](const int os, const int ks) { if (B2_ABL & 8) return xf[os][ks % KS]; return *(const bf16x8*)(smem + ya + os * 32 * B2_YPITCH + ks * 32); };
   auto rd_tr = [&](const int tensor, const int tk, const int dt) {
-    if (B2_ABL & 8) return xf[tensor][tk * 4 + dt];
+    if (B2_ABL & 8) return xf[tensor][(tk * DT + dt) % KS];
     return tr2(smem + tra[(2 * tk) & 3] + tensor * B2_TILE + (16 * tk) * B2_PITCH + dt * 64,
                smem + tra[(2 * tk + 1) & 3] + tensor * B2_TILE + (16 * tk + 8) * B2_PITCH + dt * 64);
   };
@@ -282,39 +287,54 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   using F = BoolTag<false>;
 
   // ================================================================================ dK/dV tile body
+  // VALU slots: slot N (0..15) = exp piece N + the bf16 packing of piece N - 1 | dS piece N.  VP slots go behind MFMA number M of a phase.
+  auto exp_slot = [&](auto masked_t, auto n_t, const int lo0, const int lo1) {
+    constexpr int N = decltype(n_t)::value;
+    exp_piece(masked_t, IC<((N >> 1) & 1)>{}, IC<(N >> 2)>{}, IC<(N & 1)>{}, ((N >> 1) & 1) ? lo1 : lo0);
+    if constexpr (N > 0) pack_piece(IC<(((N - 1) >> 1) & 1)>{}, IC<((N - 1) >> 2)>{}, IC<((N - 1) & 1)>{});
+  };
+  auto exp_slots = [&](auto masked_t, auto m_t, const int lo0, const int lo1) {
+    constexpr int M = decltype(m_t)::value;
+    static_for<VP>([&](auto v_t) { exp_slot(masked_t, IC<(VP * M + decltype(v_t)::value)>{}, lo0, lo1); });
+  };
+  auto ds_slots = [&](auto m_t) {
+    constexpr int M = decltype(m_t)::value;
+    static_for<VP>([&](auto v_t) {
+      constexpr int N = VP * M + decltype(v_t)::value;
+      ds_piece(T{}, IC<((N >> 1) & 1)>{}, IC<(N >> 2)>{}, IC<(N & 1)>{});
+    });
+  };
   auto body_dkv = [&](auto masked_t, const int lo0, const int lo1) {
     // ---- S = Xs X^T
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
-      static_for<8>([&](auto ks_t) {
+      static_for<KS>([&](auto ks_t) {
         constexpr int ks = decltype(ks_t)::value;
-        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+        if (ks + B2_DEPTH < KS) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
         sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
         sd_mfma<ks == 0>(s[1], a, xf[1][ks]);
-        if (ks == 5) ld_l4(0);
+        if (ks == KS - 3) ld_l4(0);
         B2_SB();
       });
     }
-    // ---- dP = Ys Y^T  ||  P = exp2(S c - lse), packed: one piece behind every MFMA
+    // ---- dP = Ys Y^T  ||  P = exp2(S c - lse), packed: VP pieces behind every MFMA
     {
       bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); b0[st] = rd_y(0, st); b1[st] = rd_y(1, st); }
-      static_for<8>([&](auto ks_t) {
+      static_for<KS>([&](auto ks_t) {
         constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
-        if (nx < 8) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
+        if (nx < KS) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
         sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
         if (ks == 0) hazard_pad(s[0], s[1]);
-        exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<0>{}, (ks & 1) ? lo1 : lo0);
-        if constexpr (ks > 0) pack_piece(IC<((ks - 1) & 1)>{}, IC<((ks - 1) / 2)>{}, IC<1>{});
+        exp_slots(masked_t, IC<(2 * ks)>{}, lo0, lo1);
         B2_SB();
         sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
-        exp_piece(masked_t, IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<1>{}, (ks & 1) ? lo1 : lo0);
-        pack_piece(IC<(ks & 1)>{}, IC<(ks / 2)>{}, IC<0>{});
-        if (ks == 6) ld_d4(0);
+        exp_slots(masked_t, IC<(2 * ks + 1)>{}, lo0, lo1);
+        if (ks == KS - 2) ld_d4(0);
         B2_SB();
       });
     }
@@ -322,18 +342,18 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
-      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(1, st >> 2, st & 3);
-      static_for<8>([&](auto st_t) {
-        constexpr int st = decltype(st_t)::value, tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
-        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx >> 2, nx & 3);
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(1, st / DT, st % DT);
+      static_for<NST>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
+        if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
         if (st == 0) pack_piece(IC<1>{}, IC<3>{}, IC<1>{});          // the last exp piece's pair (feeds tk = 1 only)
         acc_mfma<8 + dt>(a, opnd(pP[0], tk));
         if (st == 0) hazard_pad(dp[0], dp[1]);
-        ds_piece(T{}, IC<(st & 1)>{}, IC<(st / 2)>{}, IC<0>{});
+        ds_slots(IC<(2 * st)>{});
         B2_SB();
         acc_mfma<12 + dt>(a, opnd(pP[1], tk));
-        ds_piece(T{}, IC<(st & 1)>{}, IC<(st / 2)>{}, IC<1>{});
+        ds_slots(IC<(2 * st + 1)>{});
         B2_SB();
       });
     }
@@ -341,10 +361,10 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
-      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
-      static_for<8>([&](auto st_t) {
-        constexpr int st = decltype(st_t)::value, tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
-        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st / DT, st % DT);
+      static_for<NST>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
+        if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
         acc_mfma<dt>(a, opnd(pS[0], tk));
         acc_mfma<4 + dt>(a, opnd(pS[1], tk));
@@ -363,100 +383,94 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       ds_piece(sub_t, os_t, g4_t, IC<0>{});
       ds_piece(sub_t, os_t, g4_t, IC<1>{});
     };
+    // the softmax / dS work of one owner strip as 7 slots of row groups; VP slots go behind MFMA number M of a phase
+    auto grp_slot = [&](auto m_t, auto os_t, auto n_t, const int thr) {
+      constexpr int N = decltype(n_t)::value;
+      if constexpr (N == 0) exp_grp(m_t, os_t, IC<0>{}, thr);
+      if constexpr (N == 1) { ds_grp(F{}, os_t, IC<0>{}); exp_grp(m_t, os_t, IC<1>{}, thr); }
+      if constexpr (N == 2) ds_grp(F{}, os_t, IC<1>{});
+      if constexpr (N == 3) exp_grp(m_t, os_t, IC<2>{}, thr);
+      if constexpr (N == 4) ds_grp(F{}, os_t, IC<2>{});
+      if constexpr (N == 5) exp_grp(m_t, os_t, IC<3>{}, thr);
+      if constexpr (N == 6) ds_grp(F{}, os_t, IC<3>{});
+    };
+    auto grp_slots = [&](auto m_t, auto os_t, auto mf_t, const int thr) {
+      constexpr int M = decltype(mf_t)::value;
+      static_for<VP>([&](auto v_t) { grp_slot(m_t, os_t, IC<(VP * M + decltype(v_t)::value)>{}, thr); });
+    };
     // ---- dP = Ys Y^T   (Ys = V rows, Y = dO image)
     {
       bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); b0[st] = rd_y(0, st); b1[st] = rd_y(1, st); }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
-        if (nx < 8) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
-        if (ks == 0) { sd_mfma<true>(dp[0], af[cu], b0[cu]); sd_mfma<true>(dp[1], af[cu], b1[cu]); }
-        else { sd_mfma<false>(dp[0], af[cu], b0[cu]); sd_mfma<false>(dp[1], af[cu], b1[cu]); }
+      static_for<KS>([&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
+        if (nx < KS) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
+        sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
+        sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
         B2_SB();
-      }
+      });
     }
     // ---- S strip 0  ||  dP -= delta ; S strip 1  ||  strip 0: exp2, dS, pack    (K row fragments are read twice)
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+      static_for<KS>([&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value, PER = 32 / KS;      // dP values per MFMA: 4 (hd 128) | 8 (hd 64)
+        if (ks + B2_DEPTH < KS) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
-        if (ks == 0) sd_mfma<true>(s[0], a, xf[0][0]); else sd_mfma<false>(s[0], a, xf[0][ks]);
+        sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
         if (ks == 0) hazard_pad(dp[0], dp[1]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int os = ks >> 2, r = (ks & 3) * 4 + e;
+        for (int e = 0; e < PER; ++e) {
+          const int id = ks * PER + e, os = id >> 4, r = id & 15;
           dp[os][r] -= odl[os];
         }
-        B2_PIN(dp[ks >> 2]);
+        B2_PIN(dp[(ks * PER) >> 4]);
         B2_SB();
-      }
+      });
     }
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + B2_DEPTH < 8) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+      static_for<KS>([&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value;
+        if (ks + B2_DEPTH < KS) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
-        if (ks == 0) sd_mfma<true>(s[1], a, xf[1][0]); else sd_mfma<false>(s[1], a, xf[1][ks]);
+        sd_mfma<ks == 0>(s[1], a, xf[1][ks]);
         if (ks == 0) hazard_pad(s[0]);
-        if (ks == 0) exp_grp(masked_t, IC<0>{}, IC<0>{}, up0);
-        if (ks == 1) { ds_grp(F{}, IC<0>{}, IC<0>{}); exp_grp(masked_t, IC<0>{}, IC<1>{}, up0); }
-        if (ks == 2) ds_grp(F{}, IC<0>{}, IC<1>{});
-        if (ks == 3) exp_grp(masked_t, IC<0>{}, IC<2>{}, up0);
-        if (ks == 4) ds_grp(F{}, IC<0>{}, IC<2>{});
-        if (ks == 5) exp_grp(masked_t, IC<0>{}, IC<3>{}, up0);
-        if (ks == 6) ds_grp(F{}, IC<0>{}, IC<3>{});
+        grp_slots(masked_t, IC<0>{}, ks_t, up0);
         B2_SB();
-      }
+      });
     }
     // ---- dQ^T strip 0 += K^T dS  ||  strip 1: exp2, dS, pack ; then strip 1
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
-      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
-        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st / DT, st % DT);
+      static_for<NST>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
+        if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
-        if (dt == 0) acc_mfma<0>(a, opnd(pS[0], tk));
-        if (dt == 1) acc_mfma<1>(a, opnd(pS[0], tk));
-        if (dt == 2) acc_mfma<2>(a, opnd(pS[0], tk));
-        if (dt == 3) acc_mfma<3>(a, opnd(pS[0], tk));
+        acc_mfma<dt>(a, opnd(pS[0], tk));
         if (st == 0) hazard_pad(s[1]);
-        if (st == 0) exp_grp(masked_t, IC<1>{}, IC<0>{}, up1);
-        if (st == 1) { ds_grp(F{}, IC<1>{}, IC<0>{}); exp_grp(masked_t, IC<1>{}, IC<1>{}, up1); }
-        if (st == 2) ds_grp(F{}, IC<1>{}, IC<1>{});
-        if (st == 3) exp_grp(masked_t, IC<1>{}, IC<2>{}, up1);
-        if (st == 4) ds_grp(F{}, IC<1>{}, IC<2>{});
-        if (st == 5) exp_grp(masked_t, IC<1>{}, IC<3>{}, up1);
-        if (st == 6) ds_grp(F{}, IC<1>{}, IC<3>{});
+        grp_slots(masked_t, IC<1>{}, st_t, up1);
         B2_SB();
-      }
+      });
     }
     {
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
-      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st >> 2, st & 3);
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int tk = st >> 2, dt = st & 3, nx = st + B2_DEPTH;
-        if (nx < 8) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx >> 2, nx & 3);
+      for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st / DT, st % DT);
+      static_for<NST>([&](auto st_t) {
+        constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
+        if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
-        if (dt == 0) acc_mfma<4>(a, opnd(pS[1], tk));
-        if (dt == 1) acc_mfma<5>(a, opnd(pS[1], tk));
-        if (dt == 2) acc_mfma<6>(a, opnd(pS[1], tk));
-        if (dt == 3) acc_mfma<7>(a, opnd(pS[1], tk));
+        acc_mfma<4 + dt>(a, opnd(pS[1], tk));
         B2_SB();
-      }
+      });
     }
   };
 
@@ -514,7 +528,16 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   for (int os = 0; os < 2; ++os) {
     const int row = ow0 + os * 32 + l31;
     if (row >= S) continue;
-    if constexpr (DKV) {
+    if constexpr (HD == 64) {       // strips dt = 0, 1 of every accumulator group; no fused RoPE at this head dim (attn.hip refuses it)
+      bf16_t* dx = (DKV ? p.dK + (tok0 + row) * p.lddk : p.dQ + (tok0 + row) * p.lddq) + ho * 64 + hi * 16;
+      if (os == 0) { store_strip<0>(dx, p.scale); store_strip<1>(dx + 32, p.scale); }
+      else { store_strip<4>(dx, p.scale); store_strip<5>(dx + 32, p.scale); }
+      if constexpr (DKV) {
+        bf16_t* dv = p.dV + (tok0 + row) * p.lddv + ho * 64 + hi * 16;
+        if (os == 0) { store_strip<8>(dv, 1.f); store_strip<9>(dv + 32, 1.f); }
+        else { store_strip<12>(dv, 1.f); store_strip<13>(dv + 32, 1.f); }
+      }
+    } else if constexpr (DKV) {
       bf16_t* dk = p.dK + (tok0 + row) * p.lddk + ho * 128 + hi * 16;
       bf16_t* dv = p.dV + (tok0 + row) * p.lddv + ho * 128 + hi * 16;
       const bf16_t* cp = nullptr; const bf16_t* sp = nullptr;
@@ -547,7 +570,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 // Causal work per owner block is linear in its index (dQ: grows, dK/dV: shrinks): every workgroup takes a pair of blocks
 // from opposite ends, so all workgroups carry the same number of tiles.
 // Grid (heads, owner blocks, batch), head fastest: see attn_fwd2.hip — the workgroups of one head share an XCD's L2.
-template <bool DKV, bool CAUSAL>
+template <bool DKV, bool CAUSAL, int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (CAUSAL) {
@@ -556,30 +579,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true>(p, smem, pass ? small : big, blockIdx.x, blockIdx.z);
+      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, blockIdx.x, blockIdx.z);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
+    bwd2_block<DKV, false, HD>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
   }
 }
 
-void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream) {
-  static bool attr = false;
+template <bool DKV, bool CAUSAL, int HD>
+static void launch_bwd2(const AttnP& p, const dim3 grid, hipStream_t stream) {
+  static bool attr = false;          // per instantiation
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<DKV, CAUSAL, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
     attr = true;
   }
+  hipLaunchKernelGGL((attn_bwd2_kernel<DKV, CAUSAL, HD>), grid, dim3(256), B2_LDS, stream, p);
+}
+
+void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream, int hd) {
   const int nb = (p.S + 255) / 256, nkv = p.nh / p.group, gx = causal ? (nb + 1) / 2 : nb;
   const dim3 gq(p.nh, gx, p.B), gk(nkv, gx, p.B);
-  if (causal) {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, true>), gq, dim3(256), B2_LDS, stream, p);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, true>), gk, dim3(256), B2_LDS, stream, p);
+  if (hd == 64) {
+    if (causal) { launch_bwd2<false, true, 64>(p, gq, stream); launch_bwd2<true, true, 64>(p, gk, stream); }
+    else { launch_bwd2<false, false, 64>(p, gq, stream); launch_bwd2<true, false, 64>(p, gk, stream); }
   } else {
-    hipLaunchKernelGGL((attn_bwd2_kernel<false, false>), gq, dim3(256), B2_LDS, stream, p);
-    hipLaunchKernelGGL((attn_bwd2_kernel<true, false>), gk, dim3(256), B2_LDS, stream, p);
+    if (causal) { launch_bwd2<false, true, 128>(p, gq, stream); launch_bwd2<true, true, 128>(p, gk, stream); }
+    else { launch_bwd2<false, false, 128>(p, gq, stream); launch_bwd2<true, false, 128>(p, gk, stream); }
   }
 }

@@ -37,5 +37,5 @@ void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream, int h
 // hd-128 forward, one wave per SIMD with 64 query rows per wave (attn_fwd3.hip, round 5)
 void lmod_launch_attn_fwd3(const AttnP& p, int causal, hipStream_t stream);
 
-// hd-128 backward (dQ and dK/dV kernels), one wave per SIMD with 256 asm-owned accumulators (attn_bwd2.hip)
-void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream);
+// backward (dQ and dK/dV kernels), one wave per SIMD with 256 asm-owned accumulators (attn_bwd2.hip); hd 128 or 64
+void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream, int hd = 128);

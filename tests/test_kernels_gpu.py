@@ -847,6 +847,10 @@ def _attn_ref(q, k, v, scale, causal, seqlens):
     (2, 77, 2, 2, 128, False, False),          # shorter than one query block
     (1, 1100, 4, 1, 128, True, False),         # 5 owner blocks (odd: the middle one is a single pass), GQA group of 4
     (2, 520, 4, 1, 128, False, True),          # non-causal GQA group of 4 with a ragged key mask, 3 owner blocks
+    (1, 1100, 4, 1, 64, True, False),          # head dim 64 on the one-wave-per-SIMD backward: odd block count, GQA group of 4
+    (2, 520, 4, 2, 64, False, True),           # hd 64, non-causal, ragged key mask, GQA
+    (1, 2048, 2, 2, 64, True, False),          # hd 64, 8 owner blocks (4 causal pairs)
+    (2, 333, 14, 2, 64, True, True),           # the Qwen2-0.5B student's head geometry (14 heads, 2 KV heads), ragged
 ])
 def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
     ld = (nh + 2 * nkv) * hd
