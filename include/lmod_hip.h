@@ -194,6 +194,19 @@ int lmod_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* 
                        float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
                        int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
                        float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, hipStream_t stream);
+/* The same backward (cos_t / sin_t / pos all NULL: lmod_attn_bwd; all set: lmod_attn_bwd_rope) with an optional workspace for the
+ * HEAD-SPLIT form of the dK/dV kernel.  That kernel's grid is KV heads x key blocks x batch; grouped-query models with few KV heads
+ * (the reference's d2s student Qwen2-0.5B, scripts/.../dense2sparse_distillation.sh:21: 14 heads over 2 KV heads) leave half of the
+ * CUs without a workgroup.  lmod_attn_bwd_nsplit (host-side, no stream, no device work) returns into how many parts n every group
+ * of query heads is cut for these shapes (1: no split); with split_ws_bytes >= n * 2 * B * S * nkv * hd * 4 (16-byte aligned) each
+ * part runs as its own workgroup, stores fp32 partial sums into split_ws and a reduction kernel adds them in part order
+ * (deterministic).  Without the workspace (NULL / too small), with fused RoPE or with cu_seqlens this is the unsplit launch. */
+int lmod_attn_bwd_nsplit(int B, int S, int nh, int nkv, int hd, int causal);
+int lmod_attn_bwd_split(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                        float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                        int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                        float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, void* split_ws,
+                        long long split_ws_bytes, hipStream_t stream);
 
 /* Single-query attention against a KV cache (generation: llava_qwen2_moe.py:453-473 prepare_inputs_for_generation,
  * qwen2/modeling_qwen2.py:290-309 with q_len 1).  q [B, ldq] (head h at column h*hd), caches [B, smax, ld_cache] (kv head

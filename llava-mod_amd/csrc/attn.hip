@@ -693,16 +693,62 @@ static bool bwd_generic() {      // LMOD_ATTN_BWD=1: hd-128 backward through the
 #ifndef LMOD_ATTN_BWD64_DEFAULT
 #define LMOD_ATTN_BWD64_DEFAULT 2
 #endif
+static bool bwd_nosplit() {      // LMOD_ATTN_BWD_SPLIT=0: never head-split the dK/dV launch (A/B timing)
+  static const bool v = [] { const char* e = getenv("LMOD_ATTN_BWD_SPLIT"); return e && e[0] == '0'; }();
+  return v;
+}
+static int attn_cus() {
+  static const int v = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    return n;
+  }();
+  return v;
+}
 static bool bwd64_fast() {       // LMOD_ATTN_BWD64=1: hd-64 backward through the generic kernels; 2: the one-wave-per-SIMD kernels
   static const bool v = [] { const char* e = getenv("LMOD_ATTN_BWD64"); return (e && e[0] ? atoi(e) : LMOD_ATTN_BWD64_DEFAULT) != 1; }();
   return v;
+}
+
+// Head-split dK/dV launches: dK = bf16(scale * sum over parts), dV = bf16(sum over parts), parts added in index order (deterministic).
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __restrict__ ws, int nsplit, long long rows, int width,
+                                                               bf16_t* __restrict__ dK, int lddk, bf16_t* __restrict__ dV, int lddv,
+                                                               float scale) {
+  const int per_row = width >> 3;                                  // 8 features per thread
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x, n = rows * per_row;
+  if (id >= 2 * n) return;
+  const int which = id >= n;
+  const long long e = which ? id - n : id, row = e / per_row;
+  const int col = (int)(e - row * per_row) * 8;
+  const long long plane = rows * width;
+  const float* src = ws + which * plane + row * width + col;
+  f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+  for (int s = 1; s < nsplit; ++s) {
+    a += *(const f32x4*)(src + 2 * s * plane);
+    b += *(const f32x4*)(src + 2 * s * plane + 4);
+  }
+  const float m = which ? 1.f : scale;
+  const u32x4 o = {pack2bf(a[0] * m, a[1] * m), pack2bf(a[2] * m, a[3] * m), pack2bf(b[0] * m, b[1] * m), pack2bf(b[2] * m, b[3] * m)};
+  *(u32x4*)((which ? dV + row * lddv : dK + row * lddk) + col) = o;
+}
+
+// How many parts lmod_attn_bwd_split cuts every KV head's query-head group into for these shapes (1: no split).  The dK/dV kernel's
+// grid is KV heads x owner blocks (causal: pairs) x batch; with few KV heads (Qwen2-0.5B: 2) that is fewer workgroups than CUs.
+int lmod_attn_bwd_nsplit(int B, int S, int nh, int nkv, int hd, int causal) {
+  if (B < 1 || S < 1 || nkv < 1 || nh < nkv || nh % nkv || (hd != 64 && hd != 128)) return 1;
+  if (bwd_generic() || (hd == 64 && !bwd64_fast()) || bwd_nosplit()) return 1;
+  const int nb = (S + 255) / 256, gx = causal ? (nb + 1) / 2 : nb, group = nh / nkv;
+  const long long wgs = (long long)nkv * gx * B;
+  int n = 1;
+  while (n < group && n < 8 && wgs * n * 10 < 9LL * attn_cus()) ++n;
+  return n;
 }
 
 static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
                          int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
                          float scale, int causal, const void* rope_cos, const void* rope_sin, const int* rope_pos,
-                         hipStream_t stream) {
+                         void* split_ws, long long split_ws_bytes, hipStream_t stream) {
   if (!Q || !K || !V || !O || !dO || !lse || !delta_ws || !dQ || !dK || !dV) return LMOD_EINVAL;
   if (rope_pos && (!rope_cos || !rope_sin)) return LMOD_EINVAL;
   if (rope_pos && (hd != 128 || bwd_generic())) return LMOD_EUNSUPPORTED;     // fused only in the hd-128 kernels (attn_bwd2.hip)
@@ -723,7 +769,18 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)dO,
                      (const bf16_t*)O, delta_ws, B, S, nh, hd, lddo, ldo, cu_seqlens);
   if ((hd == 128 || (hd == 64 && bwd64_fast())) && !bwd_generic()) {
+    const int ns = (split_ws && !rope_pos && !cu_seqlens) ? lmod_attn_bwd_nsplit(B, S, nh, nkv, hd, causal) : 1;
+    if (ns > 1 && split_ws_bytes >= (long long)ns * 2 * B * S * nkv * hd * 4) {
+      if ((reinterpret_cast<uintptr_t>(split_ws) & 15) != 0) return LMOD_EINVAL;
+      p.split_ws = (float*)split_ws; p.nsplit = ns; p.split_rows = (long long)B * S;
+    }
     lmod_launch_attn_bwd2(p, causal, stream, hd);
+    if (p.nsplit > 1) {
+      const int width = nkv * hd;
+      const long long thr = 2 * p.split_rows * (width >> 3);
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, stream, p.split_ws, p.nsplit,
+                         p.split_rows, width, p.dK, p.lddk, p.dV, p.lddv, p.scale);
+    }
     return lmod_launch_status();
   }
   constexpr int QB = NWAVE * 32, KBLK = NWAVE * 16;
@@ -751,7 +808,7 @@ int lmod_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
                   float scale, int causal, hipStream_t stream) {
   return attn_bwd_impl(Q, K, V, O, dO, lse, delta_ws, dQ, dK, dV, seqlens, cu_seqlens, B, S, nh, nkv, hd, ldq, ldk, ldv, ldo, lddo,
-                       lddq, lddk, lddv, scale, causal, nullptr, nullptr, nullptr, stream);
+                       lddq, lddk, lddv, scale, causal, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // lmod_attn_bwd with the gradient map of the rotary embedding applied to dQ and dK before they are stored (head dim 128):
@@ -763,7 +820,20 @@ int lmod_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* 
                        float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, hipStream_t stream) {
   if (!cos_t || !sin_t || !pos) return LMOD_EINVAL;
   return attn_bwd_impl(Q, K, V, O, dO, lse, delta_ws, dQ, dK, dV, seqlens, cu_seqlens, B, S, nh, nkv, hd, ldq, ldk, ldv, ldo, lddo,
-                       lddq, lddk, lddv, scale, causal, cos_t, sin_t, pos, stream);
+                       lddq, lddk, lddv, scale, causal, cos_t, sin_t, pos, nullptr, 0, stream);
+}
+
+// lmod_attn_bwd (cos_t / sin_t / pos all NULL) or lmod_attn_bwd_rope (all set) with an optional workspace for the head-split form of
+// the dK/dV kernel: split_ws_bytes >= lmod_attn_bwd_nsplit(...) * 2 * B * S * nkv * hd * 4, 16-byte aligned.  Without it (NULL, too
+// small, a split count of 1, fused RoPE or cu_seqlens) this is the unsplit launch.
+int lmod_attn_bwd_split(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                        float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,
+                        int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv,
+                        float scale, int causal, const void* cos_t, const void* sin_t, const int* pos, void* split_ws,
+                        long long split_ws_bytes, hipStream_t stream) {
+  if ((cos_t || sin_t || pos) && (!cos_t || !sin_t || !pos)) return LMOD_EINVAL;
+  return attn_bwd_impl(Q, K, V, O, dO, lse, delta_ws, dQ, dK, dV, seqlens, cu_seqlens, B, S, nh, nkv, hd, ldq, ldk, ldv, ldo, lddo,
+                       lddq, lddk, lddv, scale, causal, cos_t, sin_t, pos, split_ws, split_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -66,6 +66,13 @@ __device__ __forceinline__ void store_strip(bf16_t* dst, const float mul) {   //
   *(u32x4*)(dst) = w0;
   *(u32x4*)(dst + 8) = w1;
 }
+template <int N>
+__device__ __forceinline__ void store_strip_f32(float* dst) {                  // the same 16 features, fp32, unscaled
+  float v[16];
+  acc_read16<N>(v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *(f32x4*)(dst + 4 * k) = (f32x4){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+}
 // RoPE backward on the strip pair (N1: features f .. f+15 < 64, N2: the same + 64) of this lane's row, in registers: the lane holds both
 // halves of every rotate_half pair.  g = the bf16-rounded gradients the plain epilogue would store; then rope_kernel's backward
 // arithmetic (rowops.hip): dx1 = g1*cos1 + g2*sin2, dx2 = g2*cos2 - g1*sin1, each product rounded to bf16 — bit-identical to
@@ -104,7 +111,7 @@ __device__ __forceinline__ void hazard_pad(f32x16& a, f32x16& b) {
 __device__ __forceinline__ void hazard_pad(f32x16& a) { asm volatile("s_nop 3" : "+v"(a)::B2_CLOB_ALL); }
 
 template <bool DKV, bool CAUSAL, int HD>
-__device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, int ho, int b) {
+__device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, int ho, int b, int sp) {
   // Head dim 64 keeps the tile images (pitches, swizzle, owner strips) and the phase order and drops what belongs to the absent upper
   // feature half: KS reduction steps in S / dP, DT 32-feature strips per accumulator group, CH 16-byte chunks per staged row.  The
   // softmax arithmetic per tile is the same, so VP of its two-element pieces go behind every MFMA instead of one.
@@ -120,13 +127,21 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   if (o0 >= S) return;
   const long long tok0 = p.cu ? (long long)p.cu[b] : (long long)b * S;
   const float c = p.scale * 1.4426950408889634f;
-  const int gsz = DKV ? p.group : 1;
+  // dK/dV kernel: the query heads h0 .. h0 + gsz - 1 of this KV head's group (all of them unless the launch is head-split)
+  int h0 = 0, gsz = DKV ? p.group : 1;
+  if constexpr (DKV) {
+    if (p.nsplit > 1) {
+      const int per = (p.group + p.nsplit - 1) / p.nsplit;
+      h0 = sp * per;
+      gsz = max(0, min(p.group, h0 + per) - h0);
+    }
+  }
 
   const bf16_t* Xo = DKV ? p.K + tok0 * p.ldk + ho * HD : p.Q + tok0 * p.ldq + ho * HD;
   const bf16_t* Yo = DKV ? p.V + tok0 * p.ldv + ho * HD : p.dO + tok0 * p.lddo + ho * HD;
   const int ldxo = DKV ? p.ldk : p.ldq, ldyo = DKV ? p.ldv : p.lddo;
-  const bf16_t* Xs = DKV ? p.Q + tok0 * p.ldq + (ho * p.group) * HD : p.K + tok0 * p.ldk + (ho / p.group) * HD;
-  const bf16_t* Ys = DKV ? p.dO + tok0 * p.lddo + (ho * p.group) * HD : p.V + tok0 * p.ldv + (ho / p.group) * HD;
+  const bf16_t* Xs = DKV ? p.Q + tok0 * p.ldq + (ho * p.group + h0) * HD : p.K + tok0 * p.ldk + (ho / p.group) * HD;
+  const bf16_t* Ys = DKV ? p.dO + tok0 * p.lddo + (ho * p.group + h0) * HD : p.V + tok0 * p.ldv + (ho / p.group) * HD;
   const int ldxs = DKV ? p.ldq : p.ldk, ldys = DKV ? p.lddo : p.ldv;
 
   // ---- owner fragments X (B operands of S): row ow0 + 32*os + l31, features ks*16 + hi*8 .. +7
@@ -180,7 +195,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   const int wa1 = B2_YIMG + (srow + 16) * B2_PITCH + ((sch ^ (((srow + 16) >> 3) & 3)) << 4);
   u32x4 xr0, xr1, yr0, yr1;
   uint32_t lsr = 0, dlr = 0;                                    // dK/dV kernel: one lse / delta value of the staged tile
-  const long long ld0 = ((long long)b * p.nh + (DKV ? ho * p.group : ho)) * p.S;
+  const long long ld0 = ((long long)b * p.nh + (DKV ? ho * p.group + h0 : ho)) * p.S;
   const __amdgpu_buffer_rsrc_t rlse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.LSE + ld0), 0, gsz * p.S * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdel = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Delta + ld0), 0, gsz * p.S * 4, 0x00020000);
   int ghh = 0, gj = first;                                      // (head, tile) of the next gload: consecutive calls
@@ -528,6 +543,19 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   for (int os = 0; os < 2; ++os) {
     const int row = ow0 + os * 32 + l31;
     if (row >= S) continue;
+    if constexpr (DKV) {
+      if (p.split_ws) {              // head-split launch: this part's fp32 sums, unscaled; attn_dkv_reduce_kernel finishes
+        const long long width = (long long)(p.nh / p.group) * HD, plane = p.split_rows * width;
+        float* wk = p.split_ws + (long long)(2 * sp) * plane + (tok0 + row) * width + ho * HD + hi * 16;
+        float* wv = wk + plane;
+        if (os == 0) {
+          static_for<DT>([&](auto dt_t) { constexpr int dt = decltype(dt_t)::value; store_strip_f32<dt>(wk + dt * 32); store_strip_f32<8 + dt>(wv + dt * 32); });
+        } else {
+          static_for<DT>([&](auto dt_t) { constexpr int dt = decltype(dt_t)::value; store_strip_f32<4 + dt>(wk + dt * 32); store_strip_f32<12 + dt>(wv + dt * 32); });
+        }
+        continue;
+      }
+    }
     if constexpr (HD == 64) {       // strips dt = 0, 1 of every accumulator group; no fused RoPE at this head dim (attn.hip refuses it)
       bf16_t* dx = (DKV ? p.dK + (tok0 + row) * p.lddk : p.dQ + (tok0 + row) * p.lddq) + ho * 64 + hi * 16;
       if (os == 0) { store_strip<0>(dx, p.scale); store_strip<1>(dx + 32, p.scale); }
@@ -573,17 +601,19 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 template <bool DKV, bool CAUSAL, int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  int ho = blockIdx.x, sp = 0;
+  if constexpr (DKV) { if (p.nsplit > 1) { ho = blockIdx.x / p.nsplit; sp = blockIdx.x - ho * p.nsplit; } }
   if constexpr (CAUSAL) {
     const int nb = (p.S + 255) / 256, x = blockIdx.y;
     const int npass = (2 * x + 1 < nb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, blockIdx.x, blockIdx.z);
+      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, ho, blockIdx.z, sp);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false, HD>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
+    bwd2_block<DKV, false, HD>(p, smem, blockIdx.y, ho, blockIdx.z, sp);
   }
 }
 
@@ -599,7 +629,7 @@ static void launch_bwd2(const AttnP& p, const dim3 grid, hipStream_t stream) {
 
 void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream, int hd) {
   const int nb = (p.S + 255) / 256, nkv = p.nh / p.group, gx = causal ? (nb + 1) / 2 : nb;
-  const dim3 gq(p.nh, gx, p.B), gk(nkv, gx, p.B);
+  const dim3 gq(p.nh, gx, p.B), gk(nkv * (p.nsplit > 1 ? p.nsplit : 1), gx, p.B);
   if (hd == 64) {
     if (causal) { launch_bwd2<false, true, 64>(p, gq, stream); launch_bwd2<true, true, 64>(p, gk, stream); }
     else { launch_bwd2<false, false, 64>(p, gq, stream); launch_bwd2<true, false, 64>(p, gk, stream); }

@@ -23,6 +23,9 @@ struct AttnP {
   float scale;
   // lmod_attn_bwd_rope: the rotary embedding's gradient map applied to dQ / dK in the backward kernels' epilogues (hd 128)
   const bf16_t* rope_cos; const bf16_t* rope_sin; const int* rope_pos;
+  // lmod_attn_bwd_split (attn_bwd2.hip): the dK/dV kernel's query-head group cut into nsplit parts, one workgroup each, that store
+  // fp32 partial sums into split_ws [nsplit][dK | dV][split_rows][nkv * hd]; a reduction kernel adds them in split order.
+  float* split_ws; int nsplit; long long split_rows;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;

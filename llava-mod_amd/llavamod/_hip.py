@@ -43,6 +43,8 @@ SIGNATURES = {
     "lmod_attn_fwd": "ppppppp" + "iiiii" + "iiii" + "f" + "i" + "p",
     "lmod_attn_bwd": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "p",
     "lmod_attn_bwd_rope": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "ppp" + "p",
+    "lmod_attn_bwd_nsplit": "iiiiii",                      # host-side query, no stream: call it through load()
+    "lmod_attn_bwd_split": "pppppppppppp" + "iiiii" + "iiiiiiii" + "f" + "i" + "ppp" + "pq" + "p",
     "lmod_splice_count": "pp" + "iiii" + "pp" + "p",
     "lmod_splice_fill": "ppp" + "iiii" + "pp" + "pppp" + "p",
     "lmod_lossplan_count": "p" + "iiiii" + "p" + "p",

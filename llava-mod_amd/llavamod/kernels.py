@@ -338,16 +338,23 @@ def attn_bwd_rope_fusable(hd):
     return hd == 128 and os.environ.get("LMOD_ATTN_BWD") != "1"
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None, cu=None, rope=None):
-    """rope = (cos_t, sin_t, pos): also apply the rotary embedding's gradient map to dq / dk in the kernels' epilogues."""
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, seqlens=None, cu=None, rope=None, split=True):
+    """rope = (cos_t, sin_t, pos): also apply the rotary embedding's gradient map to dq / dk in the kernels' epilogues.
+    split=False: never use the head-split form of the dK/dV launch (tests, A/B timing)."""
     delta = torch.empty((B, nh, S), device=q.device, dtype=torch.float32)
     args = (ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
             ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
             dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
-    if rope is None:
-        call("lmod_attn_bwd", *args)
-    else:
+    if rope is not None:
         call("lmod_attn_bwd_rope", *args, ptr(rope[0]), ptr(rope[1]), ptr(rope[2]))
+        return dq, dk, dv
+    # few KV heads (grouped-query students): the dK/dV kernel's grid is cut along the query-head group, fp32 partial sums in `ws`
+    ns = _hip.load().lmod_attn_bwd_nsplit(B, S, nh, nkv, hd, int(causal)) if (cu is None and split) else 1
+    if ns > 1:
+        ws = torch.empty(ns * 2 * B * S * nkv * hd, device=q.device, dtype=torch.float32)
+        call("lmod_attn_bwd_split", *args, None, None, None, ptr(ws), ws.numel() * 4)
+    else:
+        call("lmod_attn_bwd", *args)
     return dq, dk, dv
 
 

@@ -712,7 +712,7 @@ def test_attn_bwd_with_fused_rope_is_bit_identical_to_bwd_plus_rope(B, S, nh, nk
     pos = ((torch.arange(B * S) * 3) % 2500).to(torch.int32).to(DEV)
     ref = torch.zeros(B * S, ld, device=DEV, dtype=BF)
     K.attn_bwd(q2, k2, v2, o, do, lse, ref[:, :nh * hd], ref[:, nh * hd:(nh + nkv) * hd], ref[:, (nh + nkv) * hd:], B, S, nh, nkv, hd,
-               scale, causal, seqlens)
+               scale, causal, seqlens, split=False)      # the fused form is an unsplit launch; a head-split one re-associates fp32 sums
     K.rope_(ref, cos, sin, pos, nh + nkv, hd, backward=True)
     out = torch.zeros(B * S, ld, device=DEV, dtype=BF)
     assert K.attn_bwd_rope_fusable(hd)
@@ -876,6 +876,21 @@ def test_attn_fwd_bwd(B, S, nh, nkv, hd, causal, ragged):
     close(dqkv[:, :nh * hd].reshape(B, S, nh, hd), qf.grad, "attn dQ", rtol=2 ** -5, afrac=2 ** -6)
     close(dqkv[:, nh * hd:(nh + nkv) * hd].reshape(B, S, nkv, hd), kf.grad, "attn dK", rtol=2 ** -5, afrac=2 ** -6)
     close(dqkv[:, (nh + nkv) * hd:].reshape(B, S, nkv, hd), vf.grad, "attn dV", rtol=2 ** -5, afrac=2 ** -6)
+    if nh > nkv:
+        # grouped-query shapes: the launch above cut every group of query heads into parts (fp32 partial sums + a reduction
+        # kernel, lmod_attn_bwd_split); the unsplit launch passes the same test, leaves dQ bit-identical and dK / dV within fp32
+        # re-association (a few bf16 ulps of the largest element)
+        from llavamod import _hip
+        ns = _hip.load().lmod_attn_bwd_nsplit(B, S, nh, nkv, hd, int(causal))
+        assert ns > 1 or os.environ.get("LMOD_ATTN_BWD") == "1" or (hd == 64 and os.environ.get("LMOD_ATTN_BWD64") == "1"), ns
+        one = torch.zeros_like(qkv)
+        K.attn_bwd(q2, k2, v2, o, do, lse, one[:, :nh * hd], one[:, nh * hd:(nh + nkv) * hd],
+                   one[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, scale, causal, seqlens, split=False)
+        close(one[:, nh * hd:(nh + nkv) * hd].reshape(B, S, nkv, hd), kf.grad, "attn dK (unsplit)", rtol=2 ** -5, afrac=2 ** -6)
+        close(one[:, (nh + nkv) * hd:].reshape(B, S, nkv, hd), vf.grad, "attn dV (unsplit)", rtol=2 ** -5, afrac=2 ** -6)
+        assert torch.equal(one[:, :nh * hd], dqkv[:, :nh * hd])
+        d = (one[:, nh * hd:].float() - dqkv[:, nh * hd:].float()).abs().max().item()
+        assert d <= 2 ** -7 * dqkv[:, nh * hd:].float().abs().max().item(), d
 
 
 def test_attn_forward_one_wave_per_simd_kernel_passes_the_same_tests():
