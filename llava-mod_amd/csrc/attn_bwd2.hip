@@ -39,6 +39,10 @@
 #ifndef B2_ABL
 #define B2_ABL 0                           // timing ablations, a bit mask (WRONG RESULTS): 1 no barrier, 2 no global->LDS staging in
 #endif                                     //   the loop, 4 no exp2 / dS VALU work, 8 no operand reads from LDS
+#ifndef B2_DFOLD
+#define B2_DFOLD 1                         // hd 64: dP - delta without VALU work: -delta is the dP accumulator's INITIAL value (the MFMA's C
+#endif                                     //   operand).  dK/dV kernel: read from the tile's LDS image straight into the accumulator registers
+                                           //   during the S phase; dQ kernel: two constant blocks of -delta[own row]
 #ifndef B2_DEPTH
 #define B2_DEPTH 2                         // operand fragments are read from LDS this many steps ahead
 #endif
@@ -47,6 +51,9 @@ template <bool FIRST>
 __device__ __forceinline__ void sd_mfma(f32x16& acc, const bf16x8 a, const bf16x8 b) {
   if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b) : B2_CLOB_ALL);
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : B2_CLOB_ALL);
+}
+__device__ __forceinline__ void sd_mfma_c(f32x16& acc, const bf16x8 a, const bf16x8 b, const f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c) : B2_CLOB_ALL);
 }
 __device__ __forceinline__ bf16x8 tr2(const char* p0, const char* p1) {      // reduction slots 0-3 | 4-7
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -115,6 +122,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   // Head dim 64 keeps the tile images (pitches, swizzle, owner strips) and the phase order and drops what belongs to the absent upper
   // feature half: KS reduction steps in S / dP, DT 32-feature strips per accumulator group, CH 16-byte chunks per staged row.  The
   // softmax arithmetic per tile is the same, so VP of its two-element pieces go behind every MFMA instead of one.
+  constexpr bool DF = B2_DFOLD && HD == 64;      // hd 128 keeps its subtractions: no registers to spare (the fold costs 22 more scalar spills there)
   constexpr int KS = HD / 16, DT = HD / 32, NST = 2 * DT, CH = HD / 8, CHS = HD == 128 ? 4 : 3, VP = 128 / HD, NLD = HD / 64;
   static_assert(HD == 128 || HD == 64, "head dim 64 or 128");
   int tid = threadIdx.x;
@@ -223,7 +231,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     if constexpr (DKV) {
       if (tid < 32) {
         *(float*)(bb + B2_YIMG + B2_LD + tid * 4) = __uint_as_float(lsr) * 1.4426950408889634f;
-        *(float*)(bb + B2_YIMG + B2_LD + 128 + tid * 4) = __uint_as_float(dlr);
+        *(float*)(bb + B2_YIMG + B2_LD + 128 + tid * 4) = DF ? -__uint_as_float(dlr) : __uint_as_float(dlr);
       }
     }
   };
@@ -251,6 +259,14 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   };
 
   f32x16 s[2], dp[2];
+  constexpr bool DQC = !DKV && DF;
+  f32x16 ndl[DQC ? 2 : 1];             // dQ kernel, hd 64: -delta[own row] in every element, the C operand of the tile's first dP MFMAs
+  if constexpr (DQC) {
+#pragma unroll
+    for (int os = 0; os < 2; ++os)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ndl[os][r] = -odl[os];
+  }
   uint32_t pP[2][8], pS[2][8];         // bf16-packed P and dS: [owner strip][4 * reduction step of 16 streamed rows + dword]
   f32x4 l4c[2], d4c[2];                // dK/dV kernel: lse / delta of the 4 streamed rows of row group G4, in slot G4 & 1;
                                        // read from LDS one row group AHEAD of their use (a read placed at its use costs
@@ -288,10 +304,11 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     constexpr bool SUB = decltype(sub_t)::value;
     constexpr int OS = decltype(os_t)::value, G4 = decltype(g4_t)::value, H = decltype(h_t)::value;
     if (B2_ABL & 4) { pS[OS][2 * G4 + H] = 0x3c003c00u; return; }
-    if constexpr (SUB && DKV) { if (OS == 0 && H == 0 && G4 < 3) ld_d4(G4 + 1); }
+    if constexpr (SUB && DKV && !DF) { if (OS == 0 && H == 0 && G4 < 3) ld_d4(G4 + 1); }
     const int r = 4 * G4 + 2 * H;
-    const float v0 = s[OS][r] * (SUB ? dp[OS][r] - d4c[G4 & 1][2 * H] : dp[OS][r]);
-    const float v1 = s[OS][r + 1] * (SUB ? dp[OS][r + 1] - d4c[G4 & 1][2 * H + 1] : dp[OS][r + 1]);
+    constexpr bool SUBD = SUB && !DF;
+    const float v0 = s[OS][r] * (SUBD ? dp[OS][r] - d4c[G4 & 1][2 * H] : dp[OS][r]);
+    const float v1 = s[OS][r + 1] * (SUBD ? dp[OS][r + 1] - d4c[G4 & 1][2 * H + 1] : dp[OS][r + 1]);
     pS[OS][2 * G4 + H] = pack2bf(v0, v1);
     B2_PIN(pS[OS][2 * G4 + H]);
   };
@@ -332,6 +349,14 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
         sd_mfma<ks == 0>(s[1], a, xf[1][ks]);
         if (ks == KS - 3) ld_l4(0);
+        if constexpr (DF) {                // dP starts at -delta[streamed row]: 8 reads (4 row groups x 2 strips) spread over the S phase
+          static_for<8 / KS>([&](auto j_t) {
+            constexpr int i = ks * (8 / KS) + decltype(j_t)::value, os = i & 1, g4 = i >> 1;
+            const f32x4 v = *(const f32x4*)(smem + lda + 128 + g4 * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[os][4 * g4 + e] = v[e];
+          });
+        }
         B2_SB();
       });
     }
@@ -343,13 +368,13 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       static_for<KS>([&](auto ks_t) {
         constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
         if (nx < KS) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
-        sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
+        sd_mfma<(ks == 0 && !DF)>(dp[0], af[cu], b0[cu]);
         if (ks == 0) hazard_pad(s[0], s[1]);
         exp_slots(masked_t, IC<(2 * ks)>{}, lo0, lo1);
         B2_SB();
-        sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
+        sd_mfma<(ks == 0 && !DF)>(dp[1], af[cu], b1[cu]);
         exp_slots(masked_t, IC<(2 * ks + 1)>{}, lo0, lo1);
-        if (ks == KS - 2) ld_d4(0);
+        if (ks == KS - 2 && !DF) ld_d4(0);
         B2_SB();
       });
     }
@@ -421,8 +446,8 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       static_for<KS>([&](auto ks_t) {
         constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
         if (nx < KS) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
-        sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]);
-        sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]);
+        if constexpr (DQC && ks == 0) { sd_mfma_c(dp[0], af[cu], b0[cu], ndl[0]); sd_mfma_c(dp[1], af[cu], b1[cu], ndl[1]); }
+        else { sd_mfma<ks == 0>(dp[0], af[cu], b0[cu]); sd_mfma<ks == 0>(dp[1], af[cu], b1[cu]); }
         B2_SB();
       });
     }
@@ -436,13 +461,15 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         if (ks + B2_DEPTH < KS) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
         const bf16x8 a = af[ks % (B2_DEPTH + 1)];
         sd_mfma<ks == 0>(s[0], a, xf[0][ks]);
-        if (ks == 0) hazard_pad(dp[0], dp[1]);
+        if constexpr (!DQC) {
+          if (ks == 0) hazard_pad(dp[0], dp[1]);
 #pragma unroll
-        for (int e = 0; e < PER; ++e) {
-          const int id = ks * PER + e, os = id >> 4, r = id & 15;
-          dp[os][r] -= odl[os];
+          for (int e = 0; e < PER; ++e) {
+            const int id = ks * PER + e, os = id >> 4, r = id & 15;
+            dp[os][r] -= odl[os];
+          }
+          B2_PIN(dp[(ks * PER) >> 4]);
         }
-        B2_PIN(dp[(ks * PER) >> 4]);
         B2_SB();
       });
     }
