@@ -109,3 +109,22 @@ def test_asm_owned_accumulators_are_not_touched_by_the_compiler(tmp_path, src, a
         elif not in_asm and not line.lstrip().startswith((";", ".")) and re.search(r"(^|[\s,\[])a(\d+|\[\d+:\d+\])", line):
             bad.append(line.strip())
     assert not bad, bad[:5]
+
+
+def test_attn_bwd_head_split_plan():
+    """lmod_attn_bwd_nsplit is a host-side query (no device work): it cuts a KV head's group of query heads only while the dK/dV grid
+    (KV heads x key blocks [causal: pairs] x batch) has fewer workgroups than 0.9 x the CU count (256 without a device), never beyond
+    the group size or 8, and not at all for multi-head attention."""
+    from llavamod import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    f = _hip.load().lmod_attn_bwd_nsplit
+    assert f(16, 2048, 14, 2, 64, 1) == 2          # Qwen2-0.5B student, the d2s shell's batch: 128 workgroups -> 256
+    assert f(4, 8192, 14, 2, 64, 1) == 2
+    assert f(16, 2048, 14, 2, 64, 0) == 1          # non-causal: 8 key blocks, 256 workgroups already
+    assert f(16, 2048, 16, 16, 64, 1) == 1         # one query head per KV head: nothing to cut
+    assert f(16, 2048, 28, 4, 128, 1) == 1         # Qwen2-7B geometry at B 16: 256 workgroups
+    assert f(1, 2048, 28, 4, 128, 1) == 7          # a single sample: down to one query head per workgroup
+    assert f(1, 256, 64, 1, 128, 1) == 8           # capped at 8 parts
+    assert f(16, 2048, 14, 2, 96, 1) == 1 and f(0, 2048, 14, 2, 64, 1) == 1 and f(16, 2048, 14, 3, 64, 1) == 1   # outside the envelope
