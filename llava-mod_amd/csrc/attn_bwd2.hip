@@ -43,6 +43,10 @@
 #define B2_DFOLD 1                         // hd 64: dP - delta without VALU work: -delta is the dP accumulator's INITIAL value (the MFMA's C
 #endif                                     //   operand).  dK/dV kernel: read from the tile's LDS image straight into the accumulator registers
                                            //   during the S phase; dQ kernel: two constant blocks of -delta[own row]
+#ifndef B2_SPREAD
+#define B2_SPREAD 0                        // (measured -0.5 ... -2 %, off; bit 1: dK/dV kernel, bit 2: dQ kernel) hd 64: the softmax / dS pieces of a tile spread over more MFMA gaps (dK/dV kernel: 12 exp pieces in
+#endif                                     //   the dP phase, 4 in the first half of dV, dS pieces in dV's second half and dK's first; dQ kernel:
+                                           //   one strip per phase — S0 | S1 || exp 0 | dP0 || exp 1 | dP1 || dS 0 | dQ0 || dS 1 | dQ1)
 #ifndef B2_DEPTH
 #define B2_DEPTH 2                         // operand fragments are read from LDS this many steps ahead
 #endif
@@ -325,16 +329,39 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     exp_piece(masked_t, IC<((N >> 1) & 1)>{}, IC<(N >> 2)>{}, IC<(N & 1)>{}, ((N >> 1) & 1) ? lo1 : lo0);
     if constexpr (N > 0) pack_piece(IC<(((N - 1) >> 1) & 1)>{}, IC<((N - 1) >> 2)>{}, IC<((N - 1) & 1)>{});
   };
-  auto exp_slots = [&](auto masked_t, auto m_t, const int lo0, const int lo1) {
-    constexpr int M = decltype(m_t)::value;
-    static_for<VP>([&](auto v_t) { exp_slot(masked_t, IC<(VP * M + decltype(v_t)::value)>{}, lo0, lo1); });
+  constexpr bool SP = (B2_SPREAD & 1) && HD == 64, SPQ = (B2_SPREAD & 2) && HD == 64;
+  auto exp_range = [&](auto masked_t, auto lo_t, auto hi_t, const int lo0, const int lo1) {       // exp slots LO .. HI - 1
+    constexpr int LO = decltype(lo_t)::value, HI = decltype(hi_t)::value;
+    if constexpr (HI > LO) static_for<HI - LO>([&](auto v_t) { exp_slot(masked_t, IC<(LO + decltype(v_t)::value)>{}, lo0, lo1); });
   };
-  auto ds_slots = [&](auto m_t) {
-    constexpr int M = decltype(m_t)::value;
-    static_for<VP>([&](auto v_t) {
-      constexpr int N = VP * M + decltype(v_t)::value;
+  auto ds_range = [&](auto lo_t, auto hi_t) {                                                       // dS pieces LO .. HI - 1
+    constexpr int LO = decltype(lo_t)::value, HI = decltype(hi_t)::value;
+    if constexpr (HI > LO) static_for<HI - LO>([&](auto v_t) {
+      constexpr int N = LO + decltype(v_t)::value;
       ds_piece(T{}, IC<((N >> 1) & 1)>{}, IC<(N >> 2)>{}, IC<(N & 1)>{});
     });
+  };
+  // which pieces go behind MFMA number M of a phase.  Plain: VP exp pieces behind every dP MFMA, VP dS pieces behind every dV MFMA.
+  // Spread (hd 64; a tile phase is 8 MFMAs, two reduction halves tk of 4): exp 0-11 behind the dP MFMAs (2, 1, 2, 1, ...), exp 12-15 behind
+  // dV's tk 0 MFMAs (they feed tk 1), dS 0-7 behind dV's tk 1 MFMAs, dS 8-15 (feed dK's tk 1) behind dK's tk 0 MFMAs.
+  auto dp_gap = [&](auto masked_t, auto m_t, const int lo0, const int lo1) {
+    constexpr int M = decltype(m_t)::value;
+    if constexpr (SP) exp_range(masked_t, IC<((3 * M + 1) / 2)>{}, IC<((3 * M + 4) / 2)>{}, lo0, lo1);
+    else exp_range(masked_t, IC<(VP * M)>{}, IC<(VP * M + VP)>{}, lo0, lo1);
+  };
+  auto dv_gap = [&](auto masked_t, auto m_t, const int lo0, const int lo1) {
+    constexpr int M = decltype(m_t)::value;
+    if constexpr (SP) {
+      if constexpr (M < 4) exp_range(masked_t, IC<(12 + M)>{}, IC<(13 + M)>{}, lo0, lo1);
+      else { if constexpr (M == 4) hazard_pad(dp[0], dp[1]); ds_range(IC<(2 * (M - 4))>{}, IC<(2 * (M - 4) + 2)>{}); }
+    } else {
+      if constexpr (M == 0) hazard_pad(dp[0], dp[1]);
+      ds_range(IC<(VP * M)>{}, IC<(VP * M + VP)>{});
+    }
+  };
+  auto dk_gap = [&](auto m_t) {
+    constexpr int M = decltype(m_t)::value;
+    if constexpr (SP && M < 4) ds_range(IC<(8 + 2 * M)>{}, IC<(10 + 2 * M)>{});
   };
   auto body_dkv = [&](auto masked_t, const int lo0, const int lo1) {
     // ---- S = Xs X^T
@@ -370,10 +397,10 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         if (nx < KS) { af[sl] = rd_ys(nx); b0[sl] = rd_y(0, nx); b1[sl] = rd_y(1, nx); }
         sd_mfma<(ks == 0 && !DF)>(dp[0], af[cu], b0[cu]);
         if (ks == 0) hazard_pad(s[0], s[1]);
-        exp_slots(masked_t, IC<(2 * ks)>{}, lo0, lo1);
+        dp_gap(masked_t, IC<(2 * ks)>{}, lo0, lo1);
         B2_SB();
         sd_mfma<(ks == 0 && !DF)>(dp[1], af[cu], b1[cu]);
-        exp_slots(masked_t, IC<(2 * ks + 1)>{}, lo0, lo1);
+        dp_gap(masked_t, IC<(2 * ks + 1)>{}, lo0, lo1);
         if (ks == KS - 2 && !DF) ld_d4(0);
         B2_SB();
       });
@@ -387,13 +414,12 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
         if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(1, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
-        if (st == 0) pack_piece(IC<1>{}, IC<3>{}, IC<1>{});          // the last exp piece's pair (feeds tk = 1 only)
+        if (st == (SP ? DT : 0)) pack_piece(IC<1>{}, IC<3>{}, IC<1>{});    // the last exp piece's pair (feeds tk = 1 only)
         acc_mfma<8 + dt>(a, opnd(pP[0], tk));
-        if (st == 0) hazard_pad(dp[0], dp[1]);
-        ds_slots(IC<(2 * st)>{});
+        dv_gap(masked_t, IC<(2 * st)>{}, lo0, lo1);
         B2_SB();
         acc_mfma<12 + dt>(a, opnd(pP[1], tk));
-        ds_slots(IC<(2 * st + 1)>{});
+        dv_gap(masked_t, IC<(2 * st + 1)>{}, lo0, lo1);
         B2_SB();
       });
     }
@@ -407,7 +433,10 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx / DT, nx % DT);
         const bf16x8 a = af[st % (B2_DEPTH + 1)];
         acc_mfma<dt>(a, opnd(pS[0], tk));
+        dk_gap(IC<(2 * st)>{});
+        if constexpr (SP) B2_SB();
         acc_mfma<4 + dt>(a, opnd(pS[1], tk));
+        dk_gap(IC<(2 * st + 1)>{});
         B2_SB();
       });
     }
@@ -438,6 +467,71 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       constexpr int M = decltype(mf_t)::value;
       static_for<VP>([&](auto v_t) { grp_slot(m_t, os_t, IC<(VP * M + decltype(v_t)::value)>{}, thr); });
     };
+    if constexpr (SPQ && !DKV) {
+      // hd 64, one owner strip per phase: every phase's MFMAs carry the other strip's softmax / dS work of ONE row group each
+      //   S0 | S1 || exp 0 | dP0 || exp 1 | dP1 || dS 0 | dQ0 || dS 1 | dQ1      (24 MFMAs; the K and V row fragments are read twice)
+      static_for<2>([&](auto os_t) {                                       // ---- S strip OS  ||  (OS = 1) exp of strip 0
+        constexpr int OS = decltype(os_t)::value;
+        bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+        for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_xs(st);
+        static_for<KS>([&](auto ks_t) {
+          constexpr int ks = decltype(ks_t)::value;
+          if (ks + B2_DEPTH < KS) af[(ks + B2_DEPTH) % (B2_DEPTH + 1)] = rd_xs(ks + B2_DEPTH);
+          sd_mfma<ks == 0>(s[OS], af[ks % (B2_DEPTH + 1)], xf[OS][ks]);
+          if constexpr (OS == 1) {
+            if (ks == 0) hazard_pad(s[0]);
+            exp_grp(masked_t, IC<0>{}, ks_t, up0);
+          }
+          B2_SB();
+        });
+      });
+      static_for<2>([&](auto os_t) {                                       // ---- dP strip OS  ||  exp of strip 1 | dS of strip 0
+        constexpr int OS = decltype(os_t)::value;
+        bf16x8 af[B2_DEPTH + 1], bb[B2_DEPTH + 1];
+#pragma unroll
+        for (int st = 0; st < B2_DEPTH; ++st) { af[st] = rd_ys(st); bb[st] = rd_y(OS, st); }
+        static_for<KS>([&](auto ks_t) {
+          constexpr int ks = decltype(ks_t)::value, nx = ks + B2_DEPTH, sl = nx % (B2_DEPTH + 1), cu = ks % (B2_DEPTH + 1);
+          if (nx < KS) { af[sl] = rd_ys(nx); bb[sl] = rd_y(OS, nx); }
+          if constexpr (DQC && ks == 0) sd_mfma_c(dp[OS], af[cu], bb[cu], ndl[OS]);
+          else sd_mfma<ks == 0>(dp[OS], af[cu], bb[cu]);
+          if constexpr (OS == 0) {
+            if (ks == 0) hazard_pad(s[1]);
+            exp_grp(masked_t, IC<1>{}, ks_t, up1);
+          } else {
+            if (ks == 0) hazard_pad(dp[0]);
+            if constexpr (!DQC) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dp[0][4 * ks + e] -= odl[0];
+            }
+            ds_grp(F{}, IC<0>{}, ks_t);
+          }
+          B2_SB();
+        });
+      });
+      static_for<2>([&](auto os_t) {                                       // ---- dQ^T strip OS += K^T dS  ||  (OS = 0) dS of strip 1
+        constexpr int OS = decltype(os_t)::value;
+        bf16x8 af[B2_DEPTH + 1];
+#pragma unroll
+        for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st / DT, st % DT);
+        static_for<NST>([&](auto st_t) {
+          constexpr int st = decltype(st_t)::value, tk = st / DT, dt = st % DT, nx = st + B2_DEPTH;
+          if (nx < NST) af[nx % (B2_DEPTH + 1)] = rd_tr(0, nx / DT, nx % DT);
+          acc_mfma<4 * OS + dt>(af[st % (B2_DEPTH + 1)], opnd(pS[OS], tk));
+          if constexpr (OS == 0) {
+            if (st == 0) hazard_pad(dp[1]);
+            if constexpr (!DQC) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dp[1][4 * st + e] -= odl[1];
+            }
+            ds_grp(F{}, IC<1>{}, st_t);
+          }
+          B2_SB();
+        });
+      });
+      return;
+    }
     // ---- dP = Ys Y^T   (Ys = V rows, Y = dO image)
     {
       bf16x8 af[B2_DEPTH + 1], b0[B2_DEPTH + 1], b1[B2_DEPTH + 1];

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+O=gpurun_out/r5u; mkdir -p $O
+cd tools
+for v in shipped b2sp1 b2sp2 shipped b2sp1 b2sp2; do
+  lib=../alt_libs/liblmod_$v.so; [ -f $lib ] || lib=../llava-mod_amd/llavamod/_lib/liblmod_hip.so
+  echo "== $v" >> ../$O/hd64_spread_ab.txt
+  LMOD_HIP_LIB=$PWD/$lib timeout 120 python bench_attn.py --hd64 2>/dev/null | grep attn_bwd >> ../$O/hd64_spread_ab.txt
+done
+cat ../$O/hd64_spread_ab.txt | python -c "
+import sys, json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('=='): print(l); continue
+    d=json.loads(l); print('  ', d['B'], d['S'], d['nh'], d['causal'], d['tflops_algo(2.5x fwd)'])
+"
