@@ -16,7 +16,7 @@
  *   - the compute-unit count per device id (the persistent GEMM grid is one workgroup per CU of the CURRENT device);
  *   - the communicator handles behind lmod_comm_* (owned by the caller through their opaque pointers);
  *   - measurement switches from the environment, documented beside their readers in csrc/ — read once at first use:
- *     LMOD_GEMM_WAVES, LMOD_ATTN_FWD, LMOD_ATTN_BWD, LMOD_ATTN_BWD64, LMOD_ATTN_BWD_SPLIT, LMOD_WGRAD_SPLIT; read at every launch (so that one test process can
+ *     LMOD_GEMM_WAVES, LMOD_ATTN_FWD, LMOD_ATTN_BWD, LMOD_ATTN_BWD64, LMOD_ATTN_BWD_SPLIT, LMOD_ATTN_XCD, LMOD_WGRAD_SPLIT; read at every launch (so that one test process can
  *     run both arms of an A/B): LMOD_GEMM_PERSIST, LMOD_GEMM_PERSIST_GROUPED, LMOD_GEMM_PERSIST_ROUNDS, LMOD_GEMM_KV4, LMOD_GEMM_SB4, LMOD_GEMM_TN4, LMOD_GEMM_TILE.
  *     Unset, they select the shipped routing.  The GEMM switches' arms are bit-identical; the attention switches choose between kernels
  *     that pass the same tests against the fp32 reference but round differently (tests/test_kernels_gpu.py).

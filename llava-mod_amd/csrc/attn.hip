@@ -653,6 +653,10 @@ extern "C" {
 #ifndef LMOD_ATTN_FWD_DEFAULT
 #define LMOD_ATTN_FWD_DEFAULT 2
 #endif
+static int xcd_remap_on() {    // LMOD_ATTN_XCD=0: hardware workgroup ids as they come, also for head counts that are no multiple of 8 (A/B timing)
+  static const int v = [] { const char* e = getenv("LMOD_ATTN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
 int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* seqlens,
                   const int* cu_seqlens, int B, int S, int nh, int nkv, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
                   int causal, hipStream_t stream) {
@@ -661,6 +665,7 @@ int lmod_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* l
   if (rc) return rc;
   if ((ldo & 7) || ldo < nh * hd) return LMOD_EINVAL;
   AttnP p = {};
+  p.xcd_remap = xcd_remap_on();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = lse;
   p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
@@ -758,6 +763,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
       lddq < nh * hd || lddk < nkv * hd || lddv < nkv * hd) return LMOD_EINVAL;
   if ((long long)S * lddo * 2 >= 0x7fffffffLL) return LMOD_EUNSUPPORTED;
   AttnP p = {};
+  p.xcd_remap = xcd_remap_on();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = (float*)lse;
   p.dO = (const bf16_t*)dO; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
   p.seqlens = seqlens; p.cu = cu_seqlens; p.B = B; p.S = S; p.nh = nh; p.group = nh / nkv;

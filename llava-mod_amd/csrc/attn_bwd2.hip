@@ -722,19 +722,21 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 template <bool DKV, bool CAUSAL, int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int ho = blockIdx.x, sp = 0;
-  if constexpr (DKV) { if (p.nsplit > 1) { ho = blockIdx.x / p.nsplit; sp = blockIdx.x - ho * p.nsplit; } }
+  int bx, by, bz;
+  xcd_work_id(p.xcd_remap, bx, by, bz);
+  int ho = bx, sp = 0;
+  if constexpr (DKV) { if (p.nsplit > 1) { ho = bx / p.nsplit; sp = bx - ho * p.nsplit; } }
   if constexpr (CAUSAL) {
-    const int nb = (p.S + 255) / 256, x = blockIdx.y;
+    const int nb = (p.S + 255) / 256, x = by;
     const int npass = (2 * x + 1 < nb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, ho, blockIdx.z, sp);
+      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, ho, bz, sp);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false, HD>(p, smem, blockIdx.y, ho, blockIdx.z, sp);
+    bwd2_block<DKV, false, HD>(p, smem, by, ho, bz, sp);
   }
 }
 

@@ -26,7 +26,23 @@ struct AttnP {
   // lmod_attn_bwd_split (attn_bwd2.hip): the dK/dV kernel's query-head group cut into nsplit parts, one workgroup each, that store
   // fp32 partial sums into split_ws [nsplit][dK | dV][split_rows][nkv * hd]; a reduction kernel adds them in split order.
   float* split_ws; int nsplit; long long split_rows;
+  int xcd_remap;                 // see xcd_work_id
 };
+
+// XCD-aware work mapping for grids whose x extent (heads) is not a multiple of the 8 XCDs.  The dispatcher deals consecutive workgroup ids
+// round-robin to the XCDs; with a multiple of 8 heads as the fastest index every workgroup of a head lands on one XCD and the blocks of a
+// (batch, head) share that XCD's L2 (attn_fwd2.hip).  With 14 heads (Qwen2-0.5B) they scatter over all eight.  Here hardware id
+// -> (id % 8) * chunk + id / 8 hands every XCD a CONTIGUOUS range of the logical order (head fastest, then block, then batch), i.e.
+// whole batch items: their K / V (shared by all query heads of a KV group) are fetched into ONE private L2.
+__device__ __forceinline__ void xcd_work_id(const int on, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  const int nx = gridDim.x, ny = gridDim.y;
+  if (!on || !(nx & 7)) return;
+  const int total = nx * ny * (int)gridDim.z, lin = bx + nx * (by + ny * bz);
+  const int xcd = lin & 7, idx = lin >> 3, base = total >> 3, rem = total & 7;
+  const int l = xcd * base + min(xcd, rem) + idx, t = l / nx;
+  bx = l - t * nx; bz = t / ny; by = t - bz * ny;
+}
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <bool V> struct BoolTag { static constexpr bool value = V; };

@@ -717,8 +717,14 @@ __device__ __forceinline__ void fwd2_block(const AttnP& p, char* smem, int qb, i
 template <bool CAUSAL, int HD = 128>
 __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if F2_TRACE
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#else
+  int bx, by, bz;
+  xcd_work_id(p.xcd_remap, bx, by, bz);
+#endif
   if constexpr (CAUSAL) {
-    const int nqb = (p.S + 255) / 256, x = blockIdx.y;
+    const int nqb = (p.S + 255) / 256, x = by;
     const int npass = (2 * x + 1 < nqb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
@@ -728,12 +734,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnP p) {
       __syncthreads();
       F2_STAMP(pass * 60 + 59);
 #else
-      fwd2_block<true, HD>(p, smem, pass ? x : nqb - 1 - x, blockIdx.x, blockIdx.z);
+      fwd2_block<true, HD>(p, smem, pass ? x : nqb - 1 - x, bx, bz);
       __syncthreads();
 #endif
     }
   } else {
-    fwd2_block<false, HD>(p, smem, blockIdx.y, blockIdx.x, blockIdx.z);
+    fwd2_block<false, HD>(p, smem, by, bx, bz);
   }
 }
 
