@@ -1,4 +1,4 @@
-// Flash attention backward for head dim 128 on gfx950 (the autograd of qwen2/modeling_qwen2.py:700-708 / :290-309 that
+// Flash attention backward for head dim 128 (and 64, see the end of this comment) on gfx950 (the autograd of qwen2/modeling_qwen2.py:700-708 / :290-309 that
 // the reference gets from torch SDPA / flash-attn): dQ in one kernel, dK + dV in another, from Q, K, V, dO, the forward's
 // log-sum-exp rows and delta = rowsum(dO * O).
 //
@@ -23,6 +23,13 @@
 //   dQ:     dP (16) |  S strip 0 (8) || dP -= delta  |  S strip 1 (8) || strip 0: exp2, dS, pack
 //                   |  dQ strip 0 += (8) || strip 1: exp2, dS, pack  |  dQ strip 1 += (8)
 // One workgroup barrier per tile.  Built by hipcc_agpr.sh with "amdgpu-agpr-alloc"="256".
+//
+// Head dim 64 (round 5; Qwen2-0.5B student, CLIP tower): the same kernels with HD = 64 — images, strips and phases unchanged, 4 reduction
+// steps in S / dP, 2 feature strips per accumulator group, 32 (dK/dV) and 24 (dQ) MFMAs per tile, two VALU pieces behind every MFMA, and
+// dP - delta for free: -delta is the dP accumulator's initial value (B2_DFOLD).  The hd-128 instantiations compile to the code they had.
+// Grouped-query launches with too few dK/dV workgroups for the chip are head-split (AttnP::nsplit, lmod_attn_bwd_split in attn.hip): a
+// workgroup takes a PART of its KV head's query heads and stores fp32 partial sums; attn_dkv_reduce_kernel (attn.hip) adds the parts.
+// Work ids go through xcd_work_id (attn_common.h) when the grid's head extent is no multiple of the 8 XCDs.
 #include "attn_common.h"
 #include "attn_acc256.h"
 #include <type_traits>
