@@ -151,13 +151,137 @@ def whole_step_object(units_per_s_per_gpu, stage, E=4):
             "basis": "TFLOP per unit x units/s per GPU / 2500 TFLOP/s; executed = what the kernels run, ledger = BASELINE.md's algorithmic count"}
 
 
+def dominant_kernel_from_profile(root=ROOT):
+    """The `roofline` object describes the DOMINANT kernel, and which kernel that is comes from the committed rocprofv3 summary of
+    this very workload, not from a constant here: the top row (by total duration) of the newest
+    `profiles/rNN_final_bench_kernel_stats.csv`.  Returns {"name", "pct", "file", "family_pct"} (family = every `gemm4_kernel` /
+    `gemm4t_kernel` instantiation: one K loop, different epilogues) or None when no summary is committed."""
+    import csv
+    for r in range(20, 0, -1):
+        f = os.path.join(root, "profiles", f"r{r:02d}_final_bench_kernel_stats.csv")
+        if not os.path.exists(f):
+            continue
+        rows = [x for x in csv.DictReader(open(f)) if x.get("Name")]
+        if not rows:
+            continue
+        top = max(rows, key=lambda x: float(x["TotalDurationNs"]))
+        fam = sum(float(x["Percentage"]) for x in rows if "gemm4_kernel" in x["Name"] or "gemm4t_kernel" in x["Name"])
+        return {"name": top["Name"], "pct": float(top["Percentage"]), "file": os.path.basename(f), "family_pct": round(fam, 1)}
+    return None
+
+
+# rocprofv3 kernel name (prefix) -> how bench.py times that kernel live: (label, which launch).  The shapes are the ones each
+# instantiation spends most of its time on in config 2 (teacher layers: hidden 4096, intermediate 11008, 32 heads).
+ROOFLINE_RECIPES = {
+    "void gemm4_kernel<1, true, false>": ("swiglu", "gemm4_kernel<1> (fused SwiGLU forward: act = silu(A Wg^T) * (A Wu^T) on the stored [2I x K] "
+                                          "weight, 256x256x64 tile = 128 gate + 128 up columns, 4 waves of 128x128, K loop as one hand-placed "
+                                          "asm statement, persistent workgroups) @ teacher MLP gate+up"),
+    "void gemm4_kernel<7, true, false>": ("nt", "gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128, K loop as one hand-placed asm "
+                                          "statement, persistent workgroups from 4 rounds of the CUs up) @ teacher QKV"),
+    "void gemm4_kernel<7, false, false>": ("nt", "gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128) @ teacher QKV"),
+}
+
+
+def roofline_recipe(root=ROOT):
+    """(dominant-kernel record, recipe key, label) — falls back to the plain NT GEMM when the top row has no live recipe."""
+    dom = dominant_kernel_from_profile(root)
+    if dom:
+        for prefix, (key, label) in ROOFLINE_RECIPES.items():
+            if dom["name"].startswith(prefix):
+                return dom, key, label
+    return dom, "nt", ROOFLINE_RECIPES["void gemm4_kernel<7, true, false>"][1]
+
+
+def time_dominant_kernel(key, B, dev, reps=10):
+    """Live micro-launch of the dominant kernel with HIP events on the launch stream (torch's current stream): returns
+    (ms per launch, flops per launch, algorithmic bytes per launch, shape)."""
+    from llavamod import kernels as K
+    gm, gk = B * 2048, 4096
+    a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
+    if key == "swiglu":
+        I = 11008
+        w = torch.randn(2 * I, gk, device=dev).to(torch.bfloat16)
+        o = torch.empty(gm, I, device=dev, dtype=torch.bfloat16)
+        run = lambda: K.gemm_swiglu(a, w, act=o)               # the frozen teacher keeps no pre-activations
+        flops, algo, shape = 2.0 * gm * 2 * I * gk, (gm * gk + 2 * I * gk + gm * I) * 2, [gm, 2 * I, gk]
+    else:
+        gn = 12288
+        w = torch.randn(gn, gk, device=dev).to(torch.bfloat16)
+        o = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
+        run = lambda: K.gemm_nt(a, w, out=o)
+        flops, algo, shape = 2.0 * gm * gn * gk, gemm_algorithmic_bytes(gm, gn, gk), [gm, gn, gk]
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, flops, algo, shape
+
+
+# entry point -> (family label, argument positions) for the in-step aggregate.  Positions index the integer-argument tuple that
+# `_hip.call` records (pointers appear as 0 / 1 = NULL / set).
+_IN_STEP = {
+    "lmod_gemm_bf16_nt": "gemm4_kernel<7> plain bf16 store",
+    "lmod_gemm_bf16_nt_res": "gemm4_kernel<8> + residual add",
+    "lmod_gemm_qkv_rope_bf16": "gemm4_kernel<5> fused QKV + RoPE",
+    "lmod_gemm_swiglu_bf16": "gemm4_kernel<1> fused SwiGLU forward",
+    "lmod_gemm_swiglu_bwd_bf16": "gemm4_kernel<4> / gemm_256_kernel<4> fused SwiGLU backward",
+    "lmod_gemm_bf16_tn": "gemm4t_kernel (TN weight gradient)",
+    "lmod_gemm_wgrad_bf16_nt": "split-K weight gradient",
+    "lmod_attn_fwd": "attn_fwd2_kernel",
+    "lmod_attn_bwd": "attn_bwd2_kernel (dQ + dK/dV + delta)",
+    "lmod_attn_bwd_rope": "attn_bwd2_kernel (dQ + dK/dV + delta)",
+    "lmod_attn_bwd_split": "attn_bwd2_kernel (dQ + dK/dV + delta)",
+}
+
+
+def _in_step_row(name, a):
+    """(family, shape key, flops or None) of one traced launch; None = not counted.  Grouped launches (live rows only known on the
+    device) are timed but carry no flop count."""
+    if name == "lmod_gemm_bf16_nt_res":       # (A, W, C, bias, res, M, N, K, ...)
+        M, N, Kd, batch, grouped = a[5], a[6], a[7], 1, False
+    elif name == "lmod_gemm_bf16_nt":
+        M, N, Kd, batch, mv, kv, act, f32, accu = a[4], a[5], a[6], a[10], a[14], a[15], a[16], a[17], a[18]
+        if f32 or accu or act == 3:
+            return None
+        grouped = bool(mv or kv)
+    elif name == "lmod_gemm_qkv_rope_bf16":
+        M, N, Kd, batch, grouped = a[4], a[5], a[6], 1, False
+    elif name == "lmod_gemm_swiglu_bf16":     # N = output columns, the GEMM is 2N wide
+        M, N, Kd, batch, grouped = a[4], 2 * a[5], a[6], a[11], bool(a[16])
+    elif name == "lmod_gemm_swiglu_bwd_bf16":
+        M, N, Kd, batch, grouped = a[4], a[5], a[6], a[11], bool(a[16])
+    elif name == "lmod_gemm_bf16_tn":
+        M, N, Kd, batch, grouped = a[3], a[4], a[5], a[9], bool(a[13])
+    elif name == "lmod_gemm_wgrad_bf16_nt":
+        M, N, Kd, batch, grouped = a[3], a[4], a[5], 1, False
+    elif name == "lmod_attn_fwd":
+        B, S, nh, hd, causal = a[7], a[8], a[9], a[11], a[17]
+        return _IN_STEP[name], f"B{B} S{S} nh{nh} hd{hd}" + (" causal" if causal else ""), 4.0 * B * nh * S * S * hd * (0.5 if causal else 1.0)
+    elif name in ("lmod_attn_bwd", "lmod_attn_bwd_rope", "lmod_attn_bwd_split"):
+        B, S, nh, hd, causal = a[12], a[13], a[14], a[16], a[26]
+        return _IN_STEP[name], f"B{B} S{S} nh{nh} hd{hd}" + (" causal" if causal else ""), 10.0 * B * nh * S * S * hd * (0.5 if causal else 1.0)
+    else:
+        return None
+    if name in ("lmod_gemm_bf16_nt", "lmod_gemm_bf16_nt_res"):
+        if M < 512 or N < 256 or ((M + 255) // 256) * ((N + 255) // 256) * batch < 160:
+            return None                           # routed to the small-tile kernels, not this family
+    key = f"{M}x{N}x{Kd}" + (f" x{batch}" if batch > 1 else "") + (" grouped" if grouped else "")
+    return _IN_STEP[name], key, (None if grouped else 2.0 * M * N * Kd * batch)
+
+
 def in_step_gemm_aggregate(step_fn, step_index):
-    """The dominant kernel INSIDE the step: one extra, untimed optimizer step with every `lmod_gemm_bf16_nt` / `_nt_res` launch bracketed by
-    events on its stream (`_hip.TRACE`); aggregate = sum of flops / sum of durations over the launches the library routes to
-    the plain bf16 256-tile kernel (gemm4_kernel<7>: bf16 store, no accumulate, no row / reduction masks, >= 160 tiles).  The
-    rocprofv3 figure of the same quantity is profiles/*_kernel_stats.md."""
+    """The MFMA kernels INSIDE the step: one extra, untimed optimizer step with every GEMM-family and attention launch bracketed
+    by events on its stream (`_hip.TRACE`).  Per family (one entry point = one epilogue of the shared K loop): launches, ms,
+    sum of flops / sum of durations over the launches whose flop count the host knows (grouped MoE launches are timed, their
+    live rows are device-side), and the top shapes.  The top-level `achieved` / `by_shape` stay those of the plain NT family
+    (`gemm4_kernel<7>` / `<8>`) so that the figure is comparable with earlier rounds' lines.  The rocprofv3 figure of the same
+    quantities is profiles/*_kernel_stats.md."""
     from llavamod import _hip
-    _hip.TRACE = {"names": {"lmod_gemm_bf16_nt", "lmod_gemm_bf16_nt_res"}, "rows": []}
+    _hip.TRACE = {"names": set(_IN_STEP), "rows": []}
     try:
         torch.cuda.synchronize()
         step_fn(step_index, pipelined=False)       # the frozen model's pass inline: no second stream sharing the chip with the timed launches
@@ -165,31 +289,44 @@ def in_step_gemm_aggregate(step_fn, step_index):
         rows = _hip.TRACE["rows"]
     finally:
         _hip.TRACE = None
+    fams = {}
+    for name, a, e0, e1 in rows:
+        r = _in_step_row(name, a)
+        if r is None:
+            continue
+        fam, key, fl = r
+        t = e0.elapsed_time(e1)
+        f = fams.setdefault(fam, {"launches": 0, "ms": 0.0, "fl": 0.0, "fl_ms": 0.0, "shapes": {}})
+        f["launches"] += 1; f["ms"] += t
+        if fl is not None:
+            f["fl"] += fl; f["fl_ms"] += t
+        sh = f["shapes"].setdefault(key, [0, 0.0, 0.0])
+        sh[0] += 1; sh[1] += t; sh[2] += fl or 0.0
+    if not fams:
+        return None
+
+    def shapes_of(f, n=6):
+        top = sorted(f["shapes"].items(), key=lambda kv: -kv[1][1])[:n]
+        return {k: {"launches": v[0], "ms": round(v[1], 2), "tflops": (round(v[2] / v[1] / 1e9, 1) if v[2] else None)} for k, v in top}
+
     fl = ms = 0.0
     n = 0
-    shapes = {}
-    for name, a, e0, e1 in rows:
-        if name == "lmod_gemm_bf16_nt_res":       # (A, W, C, bias, res, M, N, K, ...): the same loop, residual add in the epilogue (gemm4_kernel<8>)
-            M, N, Kd, batch = a[5], a[6], a[7], 1
-        else:
-            M, N, Kd, batch, mv, kv, act, f32, accu = a[4], a[5], a[6], a[10], a[14], a[15], a[16], a[17], a[18]
-            if f32 or accu or mv or kv or act == 3:
-                continue
-        if M < 512 or N < 256:
-            continue
-        if ((M + 255) // 256) * ((N + 255) // 256) * batch < 160:
-            continue
-        t = e0.elapsed_time(e1)
-        fl += 2.0 * M * N * Kd * batch; ms += t; n += 1
-        k = f"{M}x{N}x{Kd}"
-        s = shapes.setdefault(k, [0, 0.0, 0.0])
-        s[0] += 1; s[1] += t; s[2] += 2.0 * M * N * Kd * batch
-    if not n:
-        return None
-    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
-    return {"kernel": "gemm4_kernel<7> / <8> (plain bf16 store / + residual add in the epilogue) launches of ONE optimizer step (events around every launch; teacher pass inline for this step, so no second stream shares the chip)",
-            "launches": n, "ms": round(ms, 2), "achieved": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-            "by_shape": {k: {"launches": v[0], "ms": round(v[1], 2), "tflops": round(v[2] / v[1] / 1e9, 1)} for k, v in top}}
+    plain = {}
+    for fam in ("gemm4_kernel<7> plain bf16 store", "gemm4_kernel<8> + residual add"):
+        if fam in fams:
+            fl += fams[fam]["fl"]; ms += fams[fam]["fl_ms"]; n += fams[fam]["launches"]
+            for k, v in fams[fam]["shapes"].items():
+                s_ = plain.setdefault(k, [0, 0.0, 0.0]); s_[0] += v[0]; s_[1] += v[1]; s_[2] += v[2]
+    out = {"kernel": "gemm4_kernel<7> / <8> (plain bf16 store / + residual add in the epilogue) launches of ONE optimizer step (events around every launch; teacher pass inline for this step, so no second stream shares the chip)",
+           "launches": n, "ms": round(ms, 2),
+           "achieved": round(fl / ms / 1e9, 1) if ms else None, "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4) if ms else None,
+           "by_shape": shapes_of({"shapes": plain})}
+    out["families"] = {fam: {"launches": f["launches"], "ms": round(f["ms"], 2),
+                             "achieved": round(f["fl"] / f["fl_ms"] / 1e9, 1) if f["fl_ms"] else None,
+                             "frac": round(f["fl"] / f["fl_ms"] / 1e9 / PEAK_BF16_TFLOPS, 4) if f["fl_ms"] else None,
+                             "by_shape": shapes_of(f, 4)}
+                       for fam, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+    return out
 
 
 def time_optimizer(gb, opt, grad_div, reps=3):
@@ -831,23 +968,11 @@ def main():
     # Everything below that LAUNCHES work runs on EVERY rank: the in-step aggregate is one more optimizer step and the optimizer timing
     # runs the sharded AdamW with its all-gathers — at N > 1 both contain collectives, and a rank that ran them alone would wait for its
     # peers forever (rounds 4's bench did exactly that on rank 0; the N > 1 lines of round 3 predate it).  Only rank 0 reports.
-    # dominant kernel (the plain bf16 NT GEMM: gemm4_kernel<7>, ~28 % of GPU time in profiles/) at the shape it spends most time on —
-    # the teacher's fused QKV projection — measured live with HIP events on the launch stream (torch's current stream)
-    gm, gn, gk = B * 2048, 12288, 4096
-    a = torch.randn(gm, gk, device=dev).to(torch.bfloat16)
-    w = torch.randn(gn, gk, device=dev).to(torch.bfloat16)
-    o = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
-    for _ in range(2):
-        K.gemm_nt(a, w, out=o)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        K.gemm_nt(a, w, out=o)
-    e1.record()
-    torch.cuda.synchronize()
-    gemm_ms = e0.elapsed_time(e1) / 10
-    gemm_tf = 2.0 * gm * gn * gk / (gemm_ms * 1e-3) / 1e12
-    del a, w, o
+    # dominant kernel = the top row of the committed rocprofv3 summary of this workload (`roofline_recipe`), at the shape it spends
+    # most of its time on, measured live with HIP events on the launch stream (torch's current stream)
+    dom, dom_key, dom_label = roofline_recipe()
+    gemm_ms, dom_flops, algo_bytes, dom_shape = time_dominant_kernel(dom_key, B, dev)
+    gemm_tf = dom_flops / (gemm_ms * 1e-3) / 1e12
     in_step = in_step_gemm_aggregate(step, args.warmup + args.steps)
     optimizer_ms = time_optimizer(gb, opt, world * A)
     if world > 1:
@@ -858,17 +983,19 @@ def main():
         ledger = TFLOP_PER_SAMPLE_LEDGER * (2.0 if args.stage == "dpo" else 1.0)      # DPO: 105.96 TFLOP per pair
         achieved = ledger * sps / world
         # HBM-side bytes per launch of that kernel come from the committed PMC passes (they cannot be collected live); the
-        # ALGORITHMIC bytes are computed here from the shape this function launches: A + B + C once, bf16
-        algo_bytes = gemm_algorithmic_bytes(gm, gn, gk)
-        traffic, traffic_note = None, f"no committed PMC pass for this shape; algorithmic {algo_bytes / 1e9:.2f} GB"
-        tp = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_final_gemm_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(t)), "")
-        if tp:
+        # ALGORITHMIC bytes are those of the launch timed above (operands and result once, bf16)
+        traffic, traffic_note = None, f"no committed PMC pass for this kernel and shape; algorithmic {algo_bytes / 1e9:.2f} GB"
+        for r_ in range(20, 0, -1):
+            tp = os.path.join(ROOT, "profiles", f"r{r_:02d}_final_gemm_traffic.json")
+            if not os.path.exists(tp):
+                continue
             tj = json.load(open(tp))
-            if tj["shape"] == [gm, gn, gk]:
+            if tj["shape"] == dom_shape and tj["kernel"].split("<")[1][:1] == dom_label.split("<")[1][:1]:
                 traffic = round((tj["fetch_bytes_corrected"] + tj["write_bytes"]) / 1e9, 2)
                 traffic_note = (f"GB per launch at the L2/fabric boundary (Infinity-Cache hits included), {tj['source']}; "
-                                f"algorithmic (A + B + C once, bf16) {algo_bytes / 1e9:.2f} GB => {traffic * 1e9 / algo_bytes:.2f}x — see "
+                                f"algorithmic (operands + result once, bf16) {algo_bytes / 1e9:.2f} GB => {traffic * 1e9 / algo_bytes:.2f}x — see "
                                 f"profiles/{os.path.basename(tp).replace('gemm_traffic.json', 'pmc.md')}")
+                break
         out = {
             "metric": "distillation samples/sec (336px img + 2k ctx), 2B-MoE student / 7B teacher",
             "value": round(sps, 4), "unit": "samples/s" if args.stage == "mimic" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -892,11 +1019,13 @@ def main():
                        "trainable_params": n_train, "lm_head_rows": "loss rows only (513 of 2048 per sample)",
                        "final_loss": round(loss_val, 4),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm4_kernel<7> (bf16 NT GEMM, 256x256x64 tile, 4 waves of 128x128, K loop as one hand-placed asm statement, persistent workgroups from 4 rounds of the CUs up) @ teacher QKV [{gm}x{gn}x{gk}]",
+            "roofline": {"bound": "mfma", "kernel": f"{dom_label} [{dom_shape[0]}x{dom_shape[1]}x{dom_shape[2]}]",
+                         "dominant_by": (f"top row of profiles/{dom['file']}: `{dom['name']}` {dom['pct']} % of GPU time; "
+                                         f"gemm4 / gemm4t family (one K loop, different epilogues) {dom['family_pct']} %") if dom else "no committed kernel summary",
                          "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": round(gemm_ms, 4),
-                         "achieved_note": "live micro-launch: 10 launches at the teacher-QKV shape, HIP events on the launch stream",
+                         "achieved_note": "live micro-launch: 10 launches at this shape, HIP events on the launch stream",
                          "in_step": in_step,
                          "whole_step": whole_step_object(sps / world, args.stage, args.experts)},
             "optimizer_ms": optimizer_ms,

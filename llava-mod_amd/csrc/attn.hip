@@ -746,7 +746,10 @@ int lmod_attn_bwd_nsplit(int B, int S, int nh, int nkv, int hd, int causal) {
   const long long wgs = (long long)nkv * gx * B;
   int n = 1;
   while (n < group && n < 8 && wgs * n * 10 < 9LL * attn_cus()) ++n;
-  return n;
+  // every part must own a query head: with per = ceil(group / n) heads per part, ceil(group / per) parts are non-empty
+  // (group 7, n 5 -> per 2 -> 4 parts; a fifth would run its prologue, store zeros and grow the workspace for nothing)
+  const int per = (group + n - 1) / n;
+  return (group + per - 1) / per;
 }
 
 static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,

@@ -38,6 +38,23 @@ def _dist_rank_world():
     return 0, 1
 
 
+def job_rank(args=None):
+    """This process's rank in the whole job, for "ONE rank writes" decisions.  torch.distributed when it is initialised; otherwise
+    (INTEGRATION.md's native-communicator hosts, plain RANK / LOCAL_RANK launches) what the launcher told the process: HF's
+    `args.process_index`, then the RANK environment variable, then a non-negative `args.local_rank`.  Without this fallback every
+    process of such a run sees (0, 1) from `_dist_rank_world` and all of them write the same shards, index and config."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    pi = getattr(args, "process_index", None)
+    if isinstance(pi, int) and pi >= 0:
+        return pi
+    if os.environ.get("RANK", "").isdigit():
+        return int(os.environ["RANK"])
+    lr = getattr(args, "local_rank", None)
+    return lr if isinstance(lr, int) and lr > 0 else 0
+
+
 def expert_parallel_layout(model):
     """{MoE module name: (ep_size, local experts, this rank's index in its expert-parallel group)} for the layers whose experts
     are sharded over ranks (`ep_size` > 1).  A rank's `deepspeed_experts.{i}` is then GLOBAL expert `ep_rank * n_local + i`
@@ -68,10 +85,13 @@ def full_state_dict(model, writer_rank=0):
     if not layout:
         return {k: v.detach().to("cpu").contiguous() for k, v in own.items()} if rank == writer_rank else None
     ep = next(iter(layout.values()))[0]
-    if rank // ep != writer_rank // ep:          # another replica of the same experts: nothing to contribute
-        return None
+    # Group creation first, on EVERY rank: `expert_parallel_group` walks dist.new_group over all expert-parallel groups, which the
+    # whole world must call together.  A save before the first MoE forward (step-0 save, a conversion or resume script) finds the
+    # group uncached; leaving through the early return below first would have only the writer's group create it and hang.
     from .engine import expert_parallel_group
     group = expert_parallel_group(ep)
+    if rank // ep != writer_rank // ep:          # another replica of the same experts: nothing to contribute
+        return None
     out = {}
     for k, v in own.items():
         m = _EXPERT_KEY.match(k)

@@ -322,8 +322,13 @@ class _CausalLMBase(nn.Module, LlavaMetaForCausalLM):
         collectively with its experts gathered under global indices (`checkpoint.save_checkpoint`)."""
         from ...checkpoint import _dist_rank_world, save_checkpoint
         files = save_checkpoint(self, save_directory, max_shard_bytes=max_shard_bytes, writer_rank=writer_rank)
-        if _dist_rank_world()[0] == writer_rank:
+        rank = _dist_rank_world()[0]
+        if rank == writer_rank:
             self.save_config(save_directory)
+        else:                                   # not an error (the collective save calls this on every rank), but never silent
+            import logging
+            logging.getLogger("llavamod").info("save_pretrained(%s): rank %d is not the writer (rank %d) and wrote nothing",
+                                               save_directory, rank, writer_rank)
         return files
 
     def save_mm_adapter(self, output_dir, keys_to_match=("mm_projector",)):

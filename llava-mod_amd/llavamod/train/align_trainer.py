@@ -175,7 +175,7 @@ class AlignTrainer:
         writer's expert-parallel group — EVERY rank calls this method, the group gathers the experts, and the writer saves them
         under global indices (`checkpoint.full_state_dict`)."""
         import os
-        from ..checkpoint import _dist_rank_world, expert_parallel_layout
+        from ..checkpoint import expert_parallel_layout, job_rank
         if output_dir is None:
             step = getattr(getattr(self, "state", None), "global_step", 0)
             output_dir = os.path.join(getattr(self.args, "output_dir", "."), f"checkpoint-{step}")
@@ -189,7 +189,7 @@ class AlignTrainer:
             os.makedirs(output_dir, exist_ok=True)
             model.save_config(output_dir)
             return model.save_mm_adapter(output_dir, keys_to_match=tuple(keys))
-        rank, _ = _dist_rank_world()
+        rank = job_rank(self.args)          # torch.distributed's rank, or the launcher's (process_index / RANK) when it is not initialised
         should_save = bool(getattr(self.args, "should_save", rank == 0))
         if expert_parallel_layout(model):
             return model.save_pretrained(output_dir) or None          # collective: the writer is global rank 0

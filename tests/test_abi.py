@@ -127,4 +127,5 @@ def test_attn_bwd_head_split_plan():
     assert f(16, 2048, 28, 4, 128, 1) == 1         # Qwen2-7B geometry at B 16: 256 workgroups
     assert f(1, 2048, 28, 4, 128, 1) == 7          # a single sample: down to one query head per workgroup
     assert f(1, 256, 64, 1, 128, 1) == 8           # capped at 8 parts
+    assert f(6, 2048, 14, 2, 64, 1) == 4           # 48 workgroups want 5 parts; 7 heads at ceil(7/5) = 2 per part fill only 4: no empty part
     assert f(16, 2048, 14, 2, 96, 1) == 1 and f(0, 2048, 14, 2, 64, 1) == 1 and f(16, 2048, 14, 3, 64, 1) == 1   # outside the envelope
