@@ -1001,6 +1001,9 @@ def main():
             "value": round(sps, 4), "unit": "samples/s" if args.stage == "mimic" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, seeded image/token batches)",
+            # dtype of the gradient EXCHANGE at N > 1 (accumulation is fp32 either way).  The default moved from fp32 to bf16 in round 5 (the
+            # reference's bf16 DeepSpeed engine): N > 1 lines before that moved twice the bytes and are not like-for-like
+            "grad_dtype": args.grad_dtype,
             "config": {"workload": workload_name(args.stage, args.experts, world, args.ep),
                        "batch_shape": ("dense: every sample 2048 tokens" if not args.ragged else
                                        "ragged: text lengths U[600,1473] right-padded (SURVEY 8d variant), " +

@@ -201,7 +201,13 @@ int lmod_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* 
  * CUs without a workgroup.  lmod_attn_bwd_nsplit (host-side, no stream, no device work) returns into how many parts n every group
  * of query heads is cut for these shapes (1: no split); with split_ws_bytes >= n * 2 * B * S * nkv * hd * 4 (16-byte aligned) each
  * part runs as its own workgroup, stores fp32 partial sums into split_ws and a reduction kernel adds them in part order
- * (deterministic).  Without the workspace (NULL / too small), with fused RoPE or with cu_seqlens this is the unsplit launch. */
+ * (deterministic).  Without the workspace (NULL / too small), with fused RoPE or with cu_seqlens this is the unsplit launch.
+ * The same workspace serves the dS-SPILL form (round 6) when the launch is not head-split: hd 128, no cu_seqlens, S % 256 == 0 and
+ * split_ws_bytes >= B * nh * S * S * 2 (16-byte aligned) — the dK/dV kernel then also stores dS^T (bf16, [B * nh][S keys][S queries],
+ * exactly the values its dK products consume) and dQ = scale * dS K (+ the fused RoPE gradient map) is ONE batched TN GEMM on the
+ * weight-gradient kernel's K loop; the dQ kernel, which recomputes S, dP and the exponentials, is not launched (5 matmuls
+ * instead of 7; the autograd of qwen2/modeling_qwen2.py:700-708).  Deterministic; dK / dV are bit-identical to the two-kernel form,
+ * dQ differs by fp32 summation order only.  LMOD_ATTN_DS=0 (environment, read once) keeps the two-kernel form. */
 int lmod_attn_bwd_nsplit(int B, int S, int nh, int nkv, int hd, int causal);
 int lmod_attn_bwd_split(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                         float* delta_ws, void* dQ, void* dK, void* dV, const int* seqlens, const int* cu_seqlens, int B, int S,

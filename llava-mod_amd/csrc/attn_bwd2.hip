@@ -128,8 +128,9 @@ __device__ __forceinline__ void hazard_pad(f32x16& a, f32x16& b) {
 }
 __device__ __forceinline__ void hazard_pad(f32x16& a) { asm volatile("s_nop 3" : "+v"(a)::B2_CLOB_ALL); }
 
-template <bool DKV, bool CAUSAL, int HD>
+template <bool DKV, bool CAUSAL, int HD, bool SPILL = false>
 __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, int ho, int b, int sp) {
+  static_assert(!SPILL || (DKV && HD == 128), "the dS spill belongs to the hd-128 dK/dV kernel");
   // Head dim 64 keeps the tile images (pitches, swizzle, owner strips) and the phase order and drops what belongs to the absent upper
   // feature half: KS reduction steps in S / dP, DT 32-feature strips per accumulator group, CH 16-byte chunks per staged row.  The
   // softmax arithmetic per tile is the same, so VP of its two-element pieces go behind every MFMA instead of one.
@@ -148,7 +149,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   const float c = p.scale * 1.4426950408889634f;
   // dK/dV kernel: the query heads h0 .. h0 + gsz - 1 of this KV head's group (all of them unless the launch is head-split)
   int h0 = 0, gsz = DKV ? p.group : 1;
-  if constexpr (DKV) {
+  if constexpr (DKV && !SPILL) {
     if (p.nsplit > 1) {
       const int per = (p.group + p.nsplit - 1) / p.nsplit;
       h0 = sp * per;
@@ -329,6 +330,38 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   using T = BoolTag<true>;
   using F = BoolTag<false>;
 
+  // ---- dS spill (dK/dV kernel, SPILL): the tile's dS^T — the bf16 words the dK MFMAs consume — goes to the workspace in the layout
+  //   ws[b * nh + head][query tile j (S / 32)][key strip (S / 32)][half (2)][key in strip (32)][16 queries]        (1 KiB per half block)
+  // chosen so that ONE store instruction of a wave writes ONE contiguous KiB (8 whole 128-byte lines): a lane holds, per owner strip,
+  // queries {0-3, 8-11, 16-19, 24-27} + 4 hi of the tile (r -> (r & 3) + 8 (r >> 2) + 4 hi); v_permlane32_swap exchanges the 4-query runs
+  // of the two lane halves, after which lane (key, hi) owns the 16-byte chunk hi of its key's 32-byte row in half block 0 (queries 0-15)
+  // and in half block 1 (queries 16-31).  (A [key][query] row-major image — 32 rows x 32 bytes at a 4 KiB stride per instruction — doubled
+  // this kernel's time: partial lines in 32 DRAM pages per store.)  pS is dead after the dK MFMAs that read it: the exchange is in place.
+  // gemm4t_kernel<2> (gemm.hip) reads this layout through its per-lane staging offsets.
+  constexpr bool spill = SPILL;
+  char* const ds_blk = spill ? (char*)(p.ds_ws + ((long long)b * p.nh + ho * p.group + h0) * S * S + (long long)ow0 * 32) : nullptr;
+  // (hipcc may set up an asm operand with a v_mov right in front of the statement and does not know the VALU-write -> v_permlane-read
+  // hazard inside it: the wait states are part of the statement.  Without them the first exchange of a strip read a stale register.)
+  auto ds_swap = [&](uint32_t& a, uint32_t& c) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c)); };
+  // the lane offset is recomputed from the thread id where it is used: a value hoisted to kernel entry would cost a register across the
+  // whole tile loop, and this kernel has none to spare
+  auto ds_lane = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return (uint32_t)((t & 31) * 32 + ((t >> 5) & 1) * 16);
+  };
+  auto ds_store_half = [&](char* base, const int os, const int half) {             // half 0: queries 0-15 of the tile, 1: 16-31
+    uint32_t* w = &pS[os][4 * half];
+    ds_swap(w[0], w[2]);
+    ds_swap(w[1], w[3]);
+    __builtin_nontemporal_store((u32x4){w[0], w[1], w[2], w[3]}, (u32x4*)(base + ds_lane() + (os * 2048 + half * 1024)));
+  };
+  auto ds_store_zero = [&](char* base) {                                            // a tile this wave skips (wholly above the diagonal)
+    const uint32_t lo = ds_lane();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __builtin_nontemporal_store((u32x4){0u, 0u, 0u, 0u}, (u32x4*)(base + lo + q * 1024));
+  };
+
   // ================================================================================ dK/dV tile body
   // VALU slots: slot N (0..15) = exp piece N + the bf16 packing of piece N - 1 | dS piece N.  VP slots go behind MFMA number M of a phase.
   auto exp_slot = [&](auto masked_t, auto n_t, const int lo0, const int lo1) {
@@ -370,7 +403,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     constexpr int M = decltype(m_t)::value;
     if constexpr (SP && M < 4) ds_range(IC<(8 + 2 * M)>{}, IC<(10 + 2 * M)>{});
   };
-  auto body_dkv = [&](auto masked_t, const int lo0, const int lo1) {
+  auto body_dkv = [&](auto masked_t, const int lo0, const int lo1, char* const ds_base) {
     // ---- S = Xs X^T
     {
       bf16x8 af[B2_DEPTH + 1];
@@ -444,8 +477,14 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         if constexpr (SP) B2_SB();
         acc_mfma<4 + dt>(a, opnd(pS[1], tk));
         dk_gap(IC<(2 * st + 1)>{});
+        if constexpr (DKV && HD == 128) {
+          // dS spill: the tk = 0 words (queries 0-15) have fed their last MFMA once the tk = 1 steps begin: one strip behind each of
+          // the first two of them; the tk = 1 words follow the phase
+          if constexpr (spill && tk == 1 && dt < 2) ds_store_half(ds_base, dt, 0);
+        }
         B2_SB();
       });
+      if constexpr (spill) { ds_store_half(ds_base, 0, 1); ds_store_half(ds_base, 1, 1); }
     }
   };
 
@@ -649,9 +688,12 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
       th0 = (CAUSAL ? min(len - 1, q0) : len - 1) - t0 - 4 * hi;             // row index inside the tile must be <= th
       th1 = (CAUSAL ? min(len - 1, q1) : len - 1) - t0 - 4 * hi;
     }
+    char* const ds_base = spill ? ds_blk + ((long long)hh * S * S + (long long)j * S * 32) * 2 : nullptr;      // wave-uniform: (head, query tile)
     if (!skip) {
-      if constexpr (DKV) { if (masked) body_dkv(BoolTag<true>{}, th0, th1); else body_dkv(BoolTag<false>{}, th0, th1); }
+      if constexpr (DKV) { if (masked) body_dkv(BoolTag<true>{}, th0, th1, ds_base); else body_dkv(BoolTag<false>{}, th0, th1, ds_base); }
       else { if (masked) body_dq(BoolTag<true>{}, th0, th1); else body_dq(BoolTag<false>{}, th0, th1); }
+    } else if (spill) {
+      ds_store_zero(ds_base);           // the dQ GEMM reads the whole diagonal block: what this wave skips is zero there
     }
     // the next tile lives in the other buffer
     const int flip = (it & 1) ? -B2_BUF : B2_BUF;
@@ -671,7 +713,7 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
   for (int os = 0; os < 2; ++os) {
     const int row = ow0 + os * 32 + l31;
     if (row >= S) continue;
-    if constexpr (DKV) {
+    if constexpr (DKV && !SPILL) {
       if (p.split_ws) {              // head-split launch: this part's fp32 sums, unscaled; attn_dkv_reduce_kernel finishes
         const long long width = (long long)(p.nh / p.group) * HD, plane = p.split_rows * width;
         float* wk = p.split_ws + (long long)(2 * sp) * plane + (tok0 + row) * width + ho * HD + hi * 16;
@@ -726,40 +768,45 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
 // Causal work per owner block is linear in its index (dQ: grows, dK/dV: shrinks): every workgroup takes a pair of blocks
 // from opposite ends, so all workgroups carry the same number of tiles.
 // Grid (heads, owner blocks, batch), head fastest: see attn_fwd2.hip — the workgroups of one head share an XCD's L2.
-template <bool DKV, bool CAUSAL, int HD>
+template <bool DKV, bool CAUSAL, int HD, bool SPILL = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd2_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bx, by, bz;
   xcd_work_id(p.xcd_remap, bx, by, bz);
   int ho = bx, sp = 0;
-  if constexpr (DKV) { if (p.nsplit > 1) { ho = bx / p.nsplit; sp = bx - ho * p.nsplit; } }
+  if constexpr (DKV && !SPILL) { if (p.nsplit > 1) { ho = bx / p.nsplit; sp = bx - ho * p.nsplit; } }
   if constexpr (CAUSAL) {
     const int nb = (p.S + 255) / 256, x = by;
     const int npass = (2 * x + 1 < nb) ? 2 : 1;
 #pragma nounroll
     for (int pass = 0; pass < npass; ++pass) {
       const int big = DKV ? x : nb - 1 - x, small = DKV ? nb - 1 - x : x;
-      bwd2_block<DKV, true, HD>(p, smem, pass ? small : big, ho, bz, sp);
+      bwd2_block<DKV, true, HD, SPILL>(p, smem, pass ? small : big, ho, bz, sp);
       __syncthreads();
     }
   } else {
-    bwd2_block<DKV, false, HD>(p, smem, by, ho, bz, sp);
+    bwd2_block<DKV, false, HD, SPILL>(p, smem, by, ho, bz, sp);
   }
 }
 
-template <bool DKV, bool CAUSAL, int HD>
+template <bool DKV, bool CAUSAL, int HD, bool SPILL = false>
 static void launch_bwd2(const AttnP& p, const dim3 grid, hipStream_t stream) {
   static bool attr = false;          // per instantiation
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<DKV, CAUSAL, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<DKV, CAUSAL, HD, SPILL>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_bwd2_kernel<DKV, CAUSAL, HD>), grid, dim3(256), B2_LDS, stream, p);
+  hipLaunchKernelGGL((attn_bwd2_kernel<DKV, CAUSAL, HD, SPILL>), grid, dim3(256), B2_LDS, stream, p);
 }
 
 void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream, int hd) {
   const int nb = (p.S + 255) / 256, nkv = p.nh / p.group, gx = causal ? (nb + 1) / 2 : nb;
   const dim3 gq(p.nh, gx, p.B), gk(nkv * (p.nsplit > 1 ? p.nsplit : 1), gx, p.B);
+  if (p.ds_ws && hd == 128) {          // dS spill: dQ comes from lmod_launch_attn_dq_gemm
+    if (causal) launch_bwd2<true, true, 128, true>(p, gk, stream);
+    else launch_bwd2<true, false, 128, true>(p, gk, stream);
+    return;
+  }
   if (hd == 64) {
     if (causal) { launch_bwd2<false, true, 64>(p, gq, stream); launch_bwd2<true, true, 64>(p, gk, stream); }
     else { launch_bwd2<false, false, 64>(p, gq, stream); launch_bwd2<true, false, 64>(p, gk, stream); }

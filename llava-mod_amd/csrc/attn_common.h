@@ -1,4 +1,4 @@
-// Shared declarations of the attention kernels (attn.hip: hd 64 + backward; attn_fwd2.hip: hd 128 forward).
+// Shared declarations of the attention kernels (attn.hip: entry points and dispatch; attn_fwd2.hip / attn_bwd2.hip: the kernels).
 #pragma once
 #include "common.h"
 
@@ -26,6 +26,10 @@ struct AttnP {
   // lmod_attn_bwd_split (attn_bwd2.hip): the dK/dV kernel's query-head group cut into nsplit parts, one workgroup each, that store
   // fp32 partial sums into split_ws [nsplit][dK | dV][split_rows][nkv * hd]; a reduction kernel adds them in split order.
   float* split_ws; int nsplit; long long split_rows;
+  // dS spill (round 6; attn_bwd2.hip dK/dV kernel + gemm.hip lmod_launch_attn_dq_gemm): the dK/dV kernel stores dS^T — the bf16 values its
+  // dK MFMAs consume — as [B * nh][S keys][S queries]; dQ = scale * dS K is then ONE batched TN GEMM and the dQ kernel (which
+  // recomputes S, dP and the exponentials: 3 of the backward's 7 matmuls) is not launched.  NULL: the two-kernel form.
+  bf16_t* ds_ws;
   int xcd_remap;                 // see xcd_work_id
 };
 
@@ -53,8 +57,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // hd-128 forward, 32x32x16-MFMA software-pipelined kernel (attn_fwd2.hip)
 void lmod_launch_attn_fwd2(const AttnP& p, int causal, hipStream_t stream, int hd = 128);
 
-// hd-128 forward, one wave per SIMD with 64 query rows per wave (attn_fwd3.hip, round 5)
+// LAB arms (`make LAB=1`, -DLMOD_LAB=1): hd-128 forward, one wave per SIMD with 64 query rows per wave (attn_fwd3.hip, round 5), and
+// the round-1 generic 16x16x32 kernels for hd 64 / 128 (attn_lab.hip)
 void lmod_launch_attn_fwd3(const AttnP& p, int causal, hipStream_t stream);
+void lmod_launch_attn_fwd_generic(const AttnP& p, int causal, hipStream_t stream, int hd);
+void lmod_launch_attn_bwd_generic(const AttnP& p, int causal, hipStream_t stream, int hd);
 
-// backward (dQ and dK/dV kernels), one wave per SIMD with 256 asm-owned accumulators (attn_bwd2.hip); hd 128 or 64
+// backward (dQ and dK/dV kernels), one wave per SIMD with 256 asm-owned accumulators (attn_bwd2.hip); hd 128 or 64.
+// With p.ds_ws set (hd 128, dense layout, S % 256 == 0, unsplit) only the dK/dV kernel runs and spills dS^T; the caller follows with
+// lmod_launch_attn_dq_gemm (gemm.hip: gemm4t_kernel's K loop, bf16 + scale + RoPE-backward epilogue).
 void lmod_launch_attn_bwd2(const AttnP& p, int causal, hipStream_t stream, int hd = 128);
+void lmod_launch_attn_dq_gemm_raw(const void* ds_ws, const void* K, void* dQ, const int* seqlens, int B, int S, int nh, int group, int ldk,
+                                  int lddq, float scale, int causal, const void* rope_cos, const void* rope_sin, const int* rope_pos,
+                                  hipStream_t stream);                  // gemm.hip
+inline void lmod_launch_attn_dq_gemm(const AttnP& p, int causal, hipStream_t stream) {
+  lmod_launch_attn_dq_gemm_raw(p.ds_ws, p.K, p.dQ, p.seqlens, p.B, p.S, p.nh, p.group, p.ldk, p.lddq, p.scale, causal, p.rope_cos, p.rope_sin,
+                               p.rope_pos, stream);
+}

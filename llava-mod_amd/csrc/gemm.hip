@@ -37,6 +37,9 @@ struct GemmP {
   // MODE 5 (lmod_gemm_qkv_rope_bf16): rotary embedding of head-dim-128 heads in the epilogue
   const bf16_t* rope_cos; const bf16_t* rope_sin; const int* rope_pos; int rope_cols;
   int ptotal;                          // persistent gemm4 launches: tiles in all (the grid is min(ptotal, CUs))
+  // gemm4t_kernel<2> (attention dQ from the spilled dS^T, lmod_launch_attn_dq_gemm): A = dS^T [B * nh][S keys][S queries],
+  // B = the K rows of the QKV buffer, C = dQ; rope_* above as in MODE 5
+  int at_nh, at_group, at_S, at_nqb, at_causal; float at_scale; const int* at_seqlens;
 };
 
 #define GEMM_OOB 0x80000000u
@@ -2338,15 +2341,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define G4T_PIECE 1056
 #define G4T_OPB 33792
 #define G4T_STAGE 67584
-template <bool SPLIT>
+// KIND 0: C += A^T B; 1: deterministic split-K; 2: attention dQ = scale * dS K from the spilled dS^T (see GemmP::at_*): one workgroup per
+// (sample, head, 256-query block), reduction over the keys the block attends to, bf16 store with the rotary embedding's gradient map.
+template <int KIND>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4t_kernel(GemmP p) {
+  constexpr bool SPLIT = KIND == 1, ATT = KIND == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 67584
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
   const int tpb = p.tiles_m * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
+  int id = ATT ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   int bz = id / tpb, split = 0;
   if (SPLIT) { split = bz; bz = 0; id -= split * tpb; }
   int r = id - bz * tpb;
@@ -2380,14 +2386,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kbeg = split * p.kchunk;
     Kv = max(0, min(Kv - kbeg, p.kchunk));      // an empty split still arrives at the semaphore with a zero tile
   }
-  const int row0 = tm * 256, col0 = tn * 256;
-  const int nkt = (Kv + 63) >> 6;
-  if (!SPLIT && nkt == 0) return;
-  const int colsA = min(256, p.M - row0), colsB = min(256, p.N - col0);
+  int row0 = tm * 256, col0 = tn * 256;
+  int colsA = min(256, p.M - row0), colsB = min(256, p.N - col0);
   const bf16_t* Ab = p.A + (long long)bz * p.sA + (long long)kbeg * p.lda + row0;
   const bf16_t* Bb = p.B + (long long)bz * p.sB + (long long)kbeg * p.ldb + col0;
-  const uint32_t ksA = (uint32_t)p.lda * 128u, ksB = (uint32_t)p.ldb * 128u;          // bytes per K tile (64 rows)
-  const uint32_t remA = Kv > 0 ? (uint32_t)(((long long)(Kv - 1) * p.lda + colsA) * 2) : 0u;   // live bytes of the window
+  int at_b = 0, at_h = 0, at_q0 = 0;
+  if constexpr (ATT) {
+    // workgroup id = (sample, query block, head) with the head fastest: consecutive ids go to the 8 XCDs round-robin, so with a multiple
+    // of 8 heads every block of a head meets its K rows in ONE XCD's L2; the longest reductions (last query blocks) are dispatched first
+    at_h = id % p.at_nh;
+    const int r2 = id / p.at_nh, qb = p.at_nqb - 1 - r2 % p.at_nqb;
+    at_b = r2 / p.at_nqb;
+    at_q0 = qb * 256;
+    Kv = p.at_causal ? min(p.at_S, at_q0 + 256) : p.at_S;
+    if (p.at_seqlens) Kv = min(Kv, (min(p.at_seqlens[at_b], p.at_S) + 255) & ~255);     // key blocks past the sample's length were never written
+    row0 = 0; col0 = 0; colsA = 256; colsB = 128;
+    Ab = p.A + ((long long)at_b * p.at_nh + at_h) * p.at_S * p.at_S + (long long)(at_q0 >> 5) * p.at_S * 32;     // the block's first query tile
+    Bb = p.B + (long long)at_b * p.at_S * p.ldb + (at_h / p.at_group) * 128;
+  }
+  const int nkt = (Kv + 63) >> 6;
+  if (!SPLIT && !ATT && nkt == 0) return;
+  const uint32_t ksA = ATT ? 4096u : (uint32_t)p.lda * 128u, ksB = (uint32_t)p.ldb * 128u;          // bytes per K tile (64 rows)
+  // live bytes of the window.  ATT: the 8 query tiles of the block are S * 64 bytes apart, a K tile is two 2 KiB key strips in each of them
+  const uint32_t remA = ATT ? (uint32_t)(7 * p.at_S * 64 + Kv * 64)
+                            : (Kv > 0 ? (uint32_t)(((long long)(Kv - 1) * p.lda + colsA) * 2) : 0u);
   const uint32_t remB = Kv > 0 ? (uint32_t)(((long long)(Kv - 1) * p.ldb + colsB) * 2) : 0u;
 
   // staging: wave w fills sub-image w (64 columns) of both operands, 8 pieces of 8 k-rows x 128 bytes; piece j, LDS row lane >> 3
@@ -2398,8 +2420,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * ((j >> 2) + 2 * (lr >> 1)) + (j & 3) + 4 * (lr & 1);
-      voA[j] = (col < colsA) ? (uint32_t)((k * p.lda + col) * 2) : GEMM_OOB;
-      voB[j] = (col < colsB) ? (uint32_t)((k * p.ldb + col) * 2) : GEMM_OOB;
+      if constexpr (ATT) {
+        // The reduction order inside a K tile is free when both operands agree: LDS row (piece j, lane row lr) holds key 8 j + lr of
+        // the tile for A and B alike, so that a piece of A is 8 CONSECUTIVE keys of the spilled dS^T — in the dK/dV kernel's layout
+        // [query tile][key strip][half][key in strip][16 queries] (attn_bwd2.hip) four runs of 256 contiguous bytes — and a piece of
+        // B 8 consecutive K rows.
+        const int kk = 8 * j + lr;
+        voA[j] = (uint32_t)((col >> 5) * p.at_S * 64 + (kk >> 5) * 2048 + ((col >> 4) & 1) * 1024 + (kk & 31) * 32 + (col & 15) * 2);
+        voB[j] = (col < colsB) ? (uint32_t)((kk * p.ldb + col) * 2) : GEMM_OOB;
+      } else {
+        voA[j] = (col < colsA) ? (uint32_t)((k * p.lda + col) * 2) : GEMM_OOB;
+        voB[j] = (col < colsB) ? (uint32_t)((k * p.ldb + col) * 2) : GEMM_OOB;
+      }
     }
   }
   auto rsrc_at = [&](const bf16_t* base, const uint32_t ks, const uint32_t rem, const int t) {     // the window from K tile t on
@@ -2456,7 +2488,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   auto rowof = [&](int mt) { return row0 + wr * 128 + mt * 16 + li; };
   auto colof = [&](int gq, int x) { return col0 + wc * 128 + gq * 64 + x * 16 + g * 4; };
-  if constexpr (!SPLIT) {
+  if constexpr (ATT) {
+    // dQ rows at_q0 + rowof(mt) of head at_h: the 128 columns belong to the wc = 0 waves (the B image's upper half is out of range:
+    // zeros).  A lane holds features d = 16 x + 4 g .. + 3 (acc[mt][x]) and d + 64 (acc[mt][4 + x]) of its row: both halves of every
+    // rotate_half pair, so the rotary embedding's gradient map is in-lane — the arithmetic of attn_bwd2.hip's store_pair_rope / rope_kernel's
+    // backward (rowops.hip): g = bf16(acc * scale); dx1 = g1 cos1 + g2 sin2, dx2 = g2 cos2 - g1 sin1, every product rounded to bf16.
+    if (wc != 0) return;
+    bf16_t* Cb = (bf16_t*)p.C;
+    const float mul = p.at_scale;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const long long tok = (long long)at_b * p.at_S + at_q0 + rowof(mt);
+      bf16_t* dst = Cb + tok * p.ldc + at_h * 128 + g * 4;
+      if (p.rope_pos) {
+        const long long ro = (long long)p.rope_pos[tok] * 128 + g * 4;
+        const bf16_t* cp = p.rope_cos + ro; const bf16_t* sp = p.rope_sin + ro;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const u32x2 c1 = *(const u32x2*)(cp + x * 16), c2 = *(const u32x2*)(cp + 64 + x * 16);
+          const u32x2 s1 = *(const u32x2*)(sp + x * 16), s2 = *(const u32x2*)(sp + 64 + x * 16);
+          const f32x4 v1 = acc[mt][x], v2 = acc[mt][4 + x];
+          u32x2 o1, o2;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float a0 = bfround(v1[2 * k] * mul), a1 = bfround(v1[2 * k + 1] * mul);
+            const float b0 = bfround(v2[2 * k] * mul), b1 = bfround(v2[2 * k + 1] * mul);
+            o1[k] = pack2bf(bfround(a0 * bflo(c1[k])) + bfround(b0 * bflo(s2[k])), bfround(a1 * bfhi(c1[k])) + bfround(b1 * bfhi(s2[k])));
+            o2[k] = pack2bf(bfround(b0 * bflo(c2[k])) - bfround(a0 * bflo(s1[k])), bfround(b1 * bfhi(c2[k])) - bfround(a1 * bfhi(s1[k])));
+          }
+          *(u32x2*)(dst + x * 16) = o1;
+          *(u32x2*)(dst + 64 + x * 16) = o2;
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const f32x4 v1 = acc[mt][x], v2 = acc[mt][4 + x];
+          *(u32x2*)(dst + x * 16) = (u32x2){pack2bf(v1[0] * mul, v1[1] * mul), pack2bf(v1[2] * mul, v1[3] * mul)};
+          *(u32x2*)(dst + 64 + x * 16) = (u32x2){pack2bf(v2[0] * mul, v2[1] * mul), pack2bf(v2[2] * mul, v2[3] * mul)};
+        }
+      }
+    }
+  } else if constexpr (!SPLIT) {
     // fp32 C += acc: four batches of 4 pieces (16 rows x 64 columns each), every batch's loads issued ahead of the previous one's stores
     float* Cb = (float*)p.C + (long long)bz * p.sC;
     f32x4 R[4][4][4];
@@ -2601,7 +2673,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // LMOD_GEMM_WAVES=4 runs the 4-wave kernel everywhere (A/B runs).
 // Process-wide state of the launchers (all of it, see include/lmod_hip.h "State"): this routing switch, read ONCE (C++11 static
 // initialisation: thread-safe); the per-kernel-instance "LDS attribute set" flags (idempotent: a race only repeats the call); the CU
-// count per device id; and the A/B environment switches LMOD_GEMM_PERSIST / _PERSIST_ROUNDS / _KV4, read per launch.
+// count per device id; and the A/B environment switches (GemmRouting below), read once unless LMOD_GEMM_ENV_DYNAMIC=1.
 static int gemm_waves() {
   static const int w = [] {
     const char* e = getenv("LMOD_GEMM_WAVES");
@@ -2650,18 +2722,42 @@ static int gemm_cus() {
   }
   return n;
 }
+// The routing switches of this file (A/B arms of measured decisions; defaults = the measured winners) are read from the environment
+// ONCE, at the first launch (C++11 static initialisation: thread-safe) — a product process pays no getenv per launch.  A process that
+// wants to run both arms of a switch (tests/test_kernels_gpu.py, tools/bench_r5_routing.py, tools/bench_wgrad.py) sets
+// LMOD_GEMM_ENV_DYNAMIC=1 before its first launch: the switches are then re-read on every launch.
+struct GemmRouting {
+  int persist;          // LMOD_GEMM_PERSIST: plain launches with more tiles than CUs on the persistent walk (default: the build's G4_PERSIST_DEFAULT)
+  int min_rounds;       // LMOD_GEMM_PERSIST_ROUNDS: from this many rounds of the CUs up (4)
+  int grouped;          // LMOD_GEMM_PERSIST_GROUPED: 0 none, 1 fused SwiGLU forward (default), 2 plain grouped launches too
+  int sb4;              // LMOD_GEMM_SB4: dense fused SwiGLU backward on the persistent 4-wave kernel (1)
+  int kv4;              // LMOD_GEMM_KV4: k_valid batches (MoE expert weight gradients) on the 4-wave kernel (1)
+  int tn4;              // LMOD_GEMM_TN4: fp32-accumulate TN launches on gemm4t_kernel (1)
+};
+static GemmRouting read_gemm_routing() {
+  auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  GemmRouting r;
+  r.persist = geti("LMOD_GEMM_PERSIST", G4_PERSIST_DEFAULT) != 0;
+  r.min_rounds = geti("LMOD_GEMM_PERSIST_ROUNDS", 4);
+  r.grouped = geti("LMOD_GEMM_PERSIST_GROUPED", 1);
+  r.sb4 = geti("LMOD_GEMM_SB4", 1) != 0;
+  r.kv4 = geti("LMOD_GEMM_KV4", 1) != 0;
+  r.tn4 = geti("LMOD_GEMM_TN4", 1) != 0;
+  return r;
+}
+static GemmRouting gemm_routing() {
+  static const bool dynamic = [] { const char* e = getenv("LMOD_GEMM_ENV_DYNAMIC"); return e && e[0] == '1'; }();
+  static const GemmRouting once = read_gemm_routing();
+  return dynamic ? read_gemm_routing() : once;
+}
 static bool gemm_persist(const GemmP& p, long long nwg) {
   // measured (profiles/r04_gemm_loop.md): +1.5 % at 24 rounds of the CUs (teacher QKV), +4.8 % at 12 rounds with K 2048.  The first
   // threshold was 10 rounds (4 - 8 rounds measured level on the build of that day); on the final build (split-column stores) the
   // persistent form is ahead from 4 rounds up — +14 % at [32768 x 2048 x 2048] (4 rounds, 32 K tiles per output tile: the
   // prologue / epilogue share is largest there), +3.9 % at 8 rounds with K 4096, +1 % elsewhere — and in the step 10 -> 4 is
   // +0.8 ... 1.0 % on two boxes (24.18 -> 24.42, 25.08 -> 25.30 samples/s); 3 and 2 are level with 4.
-  // The two switches are read per launch (a getenv is nothing beside a launch) so that one test process can run both forms.
-  const char* e = getenv("LMOD_GEMM_PERSIST");
-  const int on = e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT;
-  const char* r = getenv("LMOD_GEMM_PERSIST_ROUNDS");
-  const int min_rounds = r ? atoi(r) : 4;
-  return on && G4_ASM && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus() && nwg >= (long long)min_rounds * gemm_cus() &&
+  const GemmRouting r = gemm_routing();
+  return r.persist && G4_ASM && !p.m_valid && !p.k_valid && p.splitk <= 1 && nwg > gemm_cus() && nwg >= (long long)r.min_rounds * gemm_cus() &&
          (p.K & 63) == 0 && p.K >= 256;
 }
 // The persistent form of a GROUPED launch (round 5; MoE capacity slabs: m_valid live rows per batch): `nwg` counts the slabs' tiles,
@@ -2669,17 +2765,12 @@ static bool gemm_persist(const GemmP& p, long long nwg) {
 // it.  Measured (profiles/r05_grouped_persistent.jsonl, config-2 MoE shapes, same box, bit-identical): the grouped fused SwiGLU
 // forward +3.1 ... 4.4 % (1229 -> 1268 TF; 128-column tiles, 32 K tiles per tile: the largest epilogue share), the plain grouped
 // launches level (down projection +4.5 / -1.0 %, gate/up dgrad -0.6 %: 256-column tiles, K 5504 / 11008).  So the default (1) routes
-// the fused SwiGLU forward only; LMOD_GEMM_PERSIST_GROUPED=2 adds the plain grouped launches, 0 keeps one tile per workgroup
-// (A/B arms; read per launch).
+// the fused SwiGLU forward only; LMOD_GEMM_PERSIST_GROUPED=2 adds the plain grouped launches, 0 keeps one tile per workgroup.
 static bool gemm_persist_grouped(const GemmP& p, long long nwg, const int mode) {
-  const char* e = getenv("LMOD_GEMM_PERSIST");
-  const char* g = getenv("LMOD_GEMM_PERSIST_GROUPED");
-  const int lvl = g ? atoi(g) : 1;
-  const int on = (e ? (atoi(e) != 0) : G4_PERSIST_DEFAULT) && (mode == 1 ? lvl >= 1 : lvl >= 2);
-  const char* r = getenv("LMOD_GEMM_PERSIST_ROUNDS");
-  const int min_rounds = r ? atoi(r) : 4;
+  const GemmRouting r = gemm_routing();
+  const int on = r.persist && (mode == 1 ? r.grouped >= 1 : r.grouped >= 2);
   return on && G4_ASM && p.m_valid && !p.k_valid && p.splitk <= 1 && p.batch >= 1 && p.batch <= GEMM_MAX_GROUPS &&
-         nwg >= (long long)min_rounds * gemm_cus() && (p.K & 63) == 0 && p.K >= 256;
+         nwg >= (long long)r.min_rounds * gemm_cus() && (p.K & 63) == 0 && p.K >= 256;
 }
 template <int MODE>
 static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
@@ -2701,8 +2792,8 @@ static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
     hipLaunchKernelGGL((gemm4_kernel<MODE, false>), dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p0);
   }
 }
-static bool gemm_sb4() { const char* e = getenv("LMOD_GEMM_SB4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 keeps the dense fused SwiGLU backward on the 8-wave kernel)
-static bool gemm_kv4() { const char* e = getenv("LMOD_GEMM_KV4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 keeps k_valid batches on the 8-wave kernel)
+static bool gemm_sb4() { return gemm_routing().sb4; }      // (A/B: 0 keeps the dense fused SwiGLU backward on the 8-wave kernel)
+static bool gemm_kv4() { return gemm_routing().kv4; }      // (A/B: 0 keeps k_valid batches on the 8-wave kernel)
 template <int MODE>
 static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a4 = false, a44 = false, a46 = false, a47 = false;
@@ -2952,17 +3043,38 @@ static int wgrad_pick_split(int M, int N, int K, int max_s) {
 // b_kmajor 2: BOTH operands reduction-major (At is dY [K x M], row stride lda; B is X [K x N]) on gemm4t_kernel — no transposed
 // copy of either.  An operand window must stay below 2 GiB (32-bit buffer offsets, out-of-range marker 0x80000000): longer
 // reductions run as several launches over K chunks (the result accumulates either way).
-static bool gemm_tn4() { const char* e = getenv("LMOD_GEMM_TN4"); return e ? atoi(e) != 0 : true; }      // (A/B: 0 = the 8-wave TN kernel)
+static bool gemm_tn4() { return gemm_routing().tn4; }      // (A/B: 0 = the 8-wave TN kernel)
 static void launch_4t(const GemmP& p, long long nwg, hipStream_t stream) {
   static bool a0 = false, a1 = false;
   if (p.splitk > 1) {
-    allow_lds(gemm4t_kernel<true>, 2 * G4T_STAGE, a1);
-    hipLaunchKernelGGL(gemm4t_kernel<true>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
+    allow_lds(gemm4t_kernel<1>, 2 * G4T_STAGE, a1);
+    hipLaunchKernelGGL(gemm4t_kernel<1>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
   } else {
-    allow_lds(gemm4t_kernel<false>, 2 * G4T_STAGE, a0);
-    hipLaunchKernelGGL(gemm4t_kernel<false>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
+    allow_lds(gemm4t_kernel<0>, 2 * G4T_STAGE, a0);
+    hipLaunchKernelGGL(gemm4t_kernel<0>, dim3((unsigned)nwg), dim3(256), 2 * G4T_STAGE, stream, p);
   }
 }
+// Attention backward, dQ from the spilled dS^T (attn_bwd2.hip's dK/dV kernel wrote it): dQ[b, t, h, :] = scale * sum_o dS[t, o] K[b, o, h_kv, :]
+// as ONE launch of gemm4t_kernel<2> — reduction-major operands exactly as stored (A = dS^T [key][query], B = K [key][feature]), one
+// workgroup per (sample, head, 256-query block), causal blocks reduce over the keys up to their own end.  N = 128 fills half of the
+// 256-column tile: the launch streams 2 S^2 B nh bytes of dS (x 1/2 causal) and is about as HBM- as MFMA-bound, so the idle half
+// costs little; against the dQ kernel it replaces (which recomputes S, dP and the exponentials) it removes 2 of the backward's 7 matmuls.
+// Declared in attn_common.h (AttnP is not visible here: plain arguments); internal C++ linkage, not part of the C-ABI.
+}  // extern "C"
+void lmod_launch_attn_dq_gemm_raw(const void* ds_ws, const void* K, void* dQ, const int* seqlens, int B, int S, int nh, int group, int ldk,
+                                  int lddq, float scale, int causal, const void* rope_cos, const void* rope_sin, const int* rope_pos,
+                                  hipStream_t stream) {
+  static bool a2 = false;
+  GemmP p = {};
+  p.A = (const bf16_t*)ds_ws; p.B = (const bf16_t*)K; p.C = dQ;
+  p.M = 256; p.N = 128; p.K = S; p.lda = S; p.ldb = ldk; p.ldc = lddq;
+  p.batch = B * nh * (S / 256); p.tiles_m = 1; p.tiles_n = 1; p.splitk = 1;
+  p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin; p.rope_pos = rope_pos;
+  p.at_nh = nh; p.at_group = group; p.at_S = S; p.at_nqb = S / 256; p.at_causal = causal; p.at_scale = scale; p.at_seqlens = seqlens;
+  allow_lds(gemm4t_kernel<2>, 2 * G4T_STAGE, a2);
+  hipLaunchKernelGGL(gemm4t_kernel<2>, dim3((unsigned)p.batch), dim3(256), 2 * G4T_STAGE, stream, p);
+}
+extern "C" {
 static inline int tn4_max_rows(int lda, int ldb) {      // reduction rows per launch that keep both operand windows below 2 GiB
   const long long ld = lda > ldb ? lda : ldb;
   const long long rows = (0x7fffffffLL - 1024) / (ld * 2);

@@ -345,17 +345,42 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, S, nh, nkv, hd, scale, causal, 
     args = (ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
             ptr(seqlens), ptr(cu), B, S, nh, nkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
             dq.stride(0), dk.stride(0), dv.stride(0), float(scale), int(causal))
-    if rope is not None:
-        call("lmod_attn_bwd_rope", *args, ptr(rope[0]), ptr(rope[1]), ptr(rope[2]))
-        return dq, dk, dv
+    rp = (ptr(rope[0]), ptr(rope[1]), ptr(rope[2])) if rope is not None else (None, None, None)
     # few KV heads (grouped-query students): the dK/dV kernel's grid is cut along the query-head group, fp32 partial sums in `ws`
-    ns = _hip.load().lmod_attn_bwd_nsplit(B, S, nh, nkv, hd, int(causal)) if (cu is None and split) else 1
+    ns = _hip.load().lmod_attn_bwd_nsplit(B, S, nh, nkv, hd, int(causal)) if (cu is None and split and rope is None) else 1
     if ns > 1:
         ws = torch.empty(ns * 2 * B * S * nkv * hd, device=q.device, dtype=torch.float32)
         call("lmod_attn_bwd_split", *args, None, None, None, ptr(ws), ws.numel() * 4)
+    elif attn_bwd_ds_fusable(B, S, nh, hd, cu):
+        # dS spill: the dK/dV kernel stores dS^T into the (cached, per device) workspace and dQ is one batched TN GEMM; the dQ kernel's
+        # recomputation of S, dP and the exponentials is gone (include/lmod_hip.h, lmod_attn_bwd_split)
+        ws = _ds_workspace(q.device, B * nh * S * S * 2)
+        call("lmod_attn_bwd_split", *args, *rp, ptr(ws), ws.numel())
+    elif rope is not None:
+        call("lmod_attn_bwd_rope", *args, *rp)
     else:
         call("lmod_attn_bwd", *args)
     return dq, dk, dv
+
+
+_DS_WS = {}
+DS_WS_MAX_BYTES = 8 << 30
+
+
+def attn_bwd_ds_fusable(B, S, nh, hd, cu=None):
+    """The dS-spill form of the attention backward (5 matmuls instead of 7) applies to hd 128, dense layouts and whole 256-row blocks;
+    its workspace is B * nh * S^2 bf16 (2.1 GB at B 16, 16 heads, S 2048), bounded here; LMOD_ATTN_DS=0 keeps the two-kernel form."""
+    return (hd == 128 and cu is None and S % 256 == 0 and os.environ.get("LMOD_ATTN_DS", "1") != "0"
+            and B * nh * S * S * 2 <= DS_WS_MAX_BYTES)
+
+
+def _ds_workspace(device, nbytes):
+    """One workspace per device, grown on demand, shared by every layer's backward (launches on one stream are ordered: the dQ GEMM of
+    layer l has read it before layer l - 1's dK/dV kernel writes it)."""
+    w = _DS_WS.get(device)
+    if w is None or w.numel() < nbytes:
+        _DS_WS[device] = w = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    return w
 
 
 def row_argmax(logits):

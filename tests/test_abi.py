@@ -81,7 +81,7 @@ def test_product_path_never_touches_the_oracle_or_the_reference():
                 assert enclosing.startswith(f"def {allowed}"), (name, i + 1, enclosing)
 
 
-@pytest.mark.parametrize("src,agprs,wpe,nkern", [("attn_fwd2.hip", 64, 2, 4), ("attn_bwd2.hip", 256, 1, 8), ("attn_fwd3.hip", 256, 1, 2)])
+@pytest.mark.parametrize("src,agprs,wpe,nkern", [("attn_fwd2.hip", 64, 2, 4), ("attn_bwd2.hip", 256, 1, 10), ("attn_fwd3.hip", 256, 1, 2)])
 def test_asm_owned_accumulators_are_not_touched_by_the_compiler(tmp_path, src, agprs, wpe, nkern):
     """attn_fwd2.hip keeps its O^T accumulators in a[0:63], attn_bwd2.hip its dQ / dK / dV accumulators in a[0:255], attn_fwd3.hip its O^T
     strips and Q fragments in a[0:191] (built with the 256-register allocation), through inline asm only (see the file headers).  Audit the ISA hipcc emits: no spills, exactly the accumulator registers the asm
@@ -129,3 +129,32 @@ def test_attn_bwd_head_split_plan():
     assert f(1, 256, 64, 1, 128, 1) == 8           # capped at 8 parts
     assert f(6, 2048, 14, 2, 64, 1) == 4           # 48 workgroups want 5 parts; 7 heads at ceil(7/5) = 2 per part fill only 4: no empty part
     assert f(16, 2048, 14, 2, 96, 1) == 1 and f(0, 2048, 14, 2, 64, 1) == 1 and f(16, 2048, 14, 3, 64, 1) == 1   # outside the envelope
+
+
+def test_product_library_ships_the_product_not_the_lab():
+    """the A/B arms that lost their measurements (round-1 generic attention kernels, the one-wave-per-SIMD
+    forward of round 5) are not compiled into liblmod_hip.so; `make LAB=1` builds them into liblmod_hip_lab.so, which exports the
+    same C-ABI and which nothing under llava-mod_amd/llavamod loads."""
+    from llavamod import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    blob = open(_hip.LIB_PATH, "rb").read()
+    for lab_kernel in (b"attn_fwd3_kernel", b"attn_bwd_dq_kernel", b"attn_bwd_dkv_kernel", b"attn_fwd_kernelILi"):
+        assert lab_kernel not in blob, lab_kernel
+    for product_kernel in (b"attn_fwd2_kernel", b"attn_bwd2_kernel", b"gemm4_kernel", b"gemm4t_kernel"):
+        assert product_kernel in blob, product_kernel
+    mk = open(os.path.join(ROOT, "llava-mod_amd", "csrc", "Makefile")).read()
+    default_srcs = next(l for l in mk.split("\n") if l.startswith("SRCS ="))
+    assert "attn_fwd3.hip" not in default_srcs and "attn_lab.hip" not in default_srcs
+    for dp, _, files in os.walk(os.path.join(ROOT, "llava-mod_amd", "llavamod")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "liblmod_hip_lab" not in open(os.path.join(dp, f), encoding="utf-8").read(), f
+    lab = os.path.join(os.path.dirname(_hip.LIB_PATH), "liblmod_hip_lab.so")
+    if os.path.exists(lab):
+        import ctypes
+        lib = ctypes.CDLL(lab)
+        for name in _header_decls():
+            assert hasattr(lib, name), name
+        assert b"attn_fwd3_kernel" in open(lab, "rb").read()

@@ -108,7 +108,7 @@ def test_every_rank_runs_what_contains_collectives():
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
     gate = main.index("    if rank == 0:\n        sps = ")
-    for call in ("in_step_gemm_aggregate(step", "time_optimizer(gb, opt", "K.gemm_nt(a, w, out=o)"):
+    for call in ("in_step_gemm_aggregate(step", "time_optimizer(gb, opt", "time_dominant_kernel(dom_key"):
         assert 0 < main.index(call) < gate, call
     tail = main[gate:]
     for call in ("in_step_gemm_aggregate(", "time_optimizer(", "timed(step,"):

@@ -600,45 +600,68 @@ def _token_logps(logits, labels):
 
 def test_per_token_logp_error_is_at_the_bf16_floor():
     """The preference stage's scalars are sigmoids of differences of SUMS of per-token log-probabilities, so one sample of them says
-    little about a kernel's accuracy (bench.py --stage dpo prints why).  The testable statistic is the per-token error itself: root mean
-    square of log p(label) against the fp32 oracle over every labelled token of a 2 x 160-token batch, for the dense teacher (no
-    routing) and for the MoE student (oracle routed with the product's own picks), held to 1.5x the same statistic of the oracle's
-    bf16 twin — the reference's own bf16 arithmetic."""
+    little about a kernel's accuracy (bench.py --stage dpo prints why).  The testable statistic is the per-token error itself, over
+    k = 4 INDEPENDENT 2 x 160-token batches (n > 1): for the dense teacher (no routing) and for the MoE student
+    (oracle routed with the product's own picks), against the fp32 oracle —
+      * root mean square of log p(label) errors, pooled over all batches, held to 1.5x the same statistic of the oracle's bf16 twin
+        (the reference's own bf16 arithmetic);
+      * NO SYSTEMATIC OFFSET: |mean error| <= 3 sigma / sqrt(n) with sigma the product's own per-token spread and n every labelled
+        token of the four batches — the mean is the quantity a sequence log-probability (a sum over tokens) inherits;
+      * every sequence's summed error (what a DPO reward sees) within 4 sigma sqrt(T) of zero."""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     vc, sc, tc = _mid_cfgs()
     o_student, o_teacher = _seeded_pair(17, sc, tc, vc)
-    batch = _mid_batch(33, 2, 160, sc.vocab_size, vc.image_size, True)
     student, teacher = U.build_hip_pair(o_student.state_dict(), o_teacher.state_dict(), sc, tc, vc, DEV)
     picks = {}
     for li, m in enumerate(student.moe_layers()):
         m.deterministic = True
         picks[li] = []
         m.register_forward_hook(lambda mod, a, o, li=li: picks[li].append((mod.last_state.idx1.cpu(), mod.last_state.idx2.cpu())))
-    hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
-    bb = _bf16_batch(batch)
     student.train(); teacher.eval()
-    with torch.no_grad():
-        hs, ht = student(**hb), teacher(**hb)
     o_student.train(); o_teacher.eval(); o_student.set_gate_noise([None, None])
     tw_s, tw_t = _bf16_twin(o_student), _bf16_twin(o_teacher)
     tw_s.train(); tw_t.eval(); tw_s.set_gate_noise([None, None])
-    for li, (om, ot) in enumerate(zip(_oracle_moes(o_student), _oracle_moes(tw_s))):
-        om.forced = list(picks[li]); ot.forced = list(picks[li])
-    with torch.no_grad():
-        os_, ot_ = o_student(**batch), o_teacher(**batch)
-        ts_, tt_ = tw_s(**bb), tw_t(**bb)
-    for name, prod, ref, twin in (("teacher", ht, ot_, tt_), ("student", hs, os_, ts_)):
-        assert torch.equal(prod.labels.cpu(), ref.labels)
-        r = _token_logps(ref.logits, ref.labels)
-        e_prod = (_token_logps(prod.logits, ref.labels) - r).double()
-        e_twin = (_token_logps(twin.logits, ref.labels) - r).double()
-        rms_p, rms_t = float(e_prod.pow(2).mean().sqrt()), float(e_twin.pow(2).mean().sqrt())
+    pooled = {"teacher": ([], []), "student": ([], [])}
+    seq_sums = {"teacher": [], "student": []}
+    for seed in (33, 34, 35, 36):
+        batch = _mid_batch(seed, 2, 160, sc.vocab_size, vc.image_size, True)
+        hb = dict(batch, images=batch["images"].to(DEV).to(torch.bfloat16))
+        bb = _bf16_batch(batch)
+        for li in picks:
+            picks[li].clear()
+        with torch.no_grad():
+            hs, ht = student(**hb), teacher(**hb)
+        for li, (om, ot) in enumerate(zip(_oracle_moes(o_student), _oracle_moes(tw_s))):
+            om.forced = list(picks[li]); ot.forced = list(picks[li])
+        with torch.no_grad():
+            os_, ot_ = o_student(**batch), o_teacher(**batch)
+            ts_, tt_ = tw_s(**bb), tw_t(**bb)
+        for name, prod, ref, twin in (("teacher", ht, ot_, tt_), ("student", hs, os_, ts_)):
+            assert torch.equal(prod.labels.cpu(), ref.labels)
+            r = _token_logps(ref.logits, ref.labels)
+            e_prod = (_token_logps(prod.logits, ref.labels) - r).double()
+            pooled[name][0].append(e_prod)
+            pooled[name][1].append((_token_logps(twin.logits, ref.labels) - r).double())
+            keep = (ref.labels[:, 1:] != IGNORE_INDEX)
+            off = 0
+            for row in keep:                                     # per sequence: the summed error a reward would inherit
+                n_row = int(row.sum())
+                if n_row:
+                    seq_sums[name].append((float(e_prod[off:off + n_row].sum()), n_row))
+                off += n_row
+    for name, (ep, et) in pooled.items():
+        e_prod, e_twin = torch.cat(ep), torch.cat(et)
         n = e_prod.numel()
-        print(f"{name}: {n} labelled tokens, per-token log-prob RMS error: product {rms_p:.5f}, bf16 twin {rms_t:.5f}; "
-              f"bias product {float(e_prod.mean()):+.5f}, twin {float(e_twin.mean()):+.5f}")
-        assert n >= 120 and rms_p <= 1.5 * rms_t + 1e-4, (name, rms_p, rms_t)
-        # and no systematic offset beyond what the spread allows: |mean| within 4 standard errors of the twin's spread
-        assert abs(float(e_prod.mean())) <= 4.0 * rms_t / n ** 0.5 + 1e-4, (name, float(e_prod.mean()), rms_t, n)
+        rms_p, rms_t = float(e_prod.pow(2).mean().sqrt()), float(e_twin.pow(2).mean().sqrt())
+        mean_p, sd_p = float(e_prod.mean()), float(e_prod.std())
+        mean_t, sd_t = float(e_twin.mean()), float(e_twin.std())
+        print(f"{name}: {n} labelled tokens over 4 batches; per-token log-prob error vs fp32: product rms {rms_p:.5f} mean {mean_p:+.6f} "
+              f"+- {sd_p / n ** 0.5:.6f} ({abs(mean_p) / (sd_p / n ** 0.5):.2f} standard errors); bf16 twin rms {rms_t:.5f} mean {mean_t:+.6f} "
+              f"+- {sd_t / n ** 0.5:.6f} ({abs(mean_t) / (sd_t / n ** 0.5):.2f} standard errors)")
+        assert n >= 480 and rms_p <= 1.5 * rms_t + 1e-4, (name, rms_p, rms_t)
+        assert abs(mean_p) <= 3.0 * sd_p / n ** 0.5 + 1e-5, (name, mean_p, sd_p, n)
+        for dev, t in seq_sums[name]:
+            assert abs(dev) <= 4.0 * max(rms_p, rms_t) * t ** 0.5 + 1e-4, (name, dev, t, rms_p)
 
 
 def test_materialising_api_matches_oracle():

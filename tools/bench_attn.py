@@ -36,7 +36,8 @@ def run(B, S, nh, nkv, hd, causal, bwd, ragged=False):
         f = lambda: K.attn_bwd(q, k, v, o, do, lse, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd],
                                dqkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, sc, causal, sl)
         t = timeit(f)
-        print(json.dumps({"kernel": "attn_bwd", "ver": os.environ.get("LMOD_ATTN_BWD", "2"), "B": B, "S": S, "nh": nh, "hd": hd, "causal": causal, "ms": round(t * 1e3, 4),
+        print(json.dumps({"kernel": "attn_bwd", "ver": os.environ.get("LMOD_ATTN_BWD", "2"),
+                          "form": "dS spill + dQ GEMM (5 matmuls)" if K.attn_bwd_ds_fusable(B, S, nh, hd) else "dQ kernel + dK/dV kernel (7 matmuls)", "B": B, "S": S, "nh": nh, "hd": hd, "causal": causal, "ms": round(t * 1e3, 4),
                           "tflops_algo(2.5x fwd)": round(2.5 * fl / t / 1e12, 1)}), flush=True)
 
 

@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llava-mod_amd"))
+os.environ.setdefault("LMOD_GEMM_ENV_DYNAMIC", "1")      # both arms of a routing switch in one process
 from llavamod import kernels as K  # noqa: E402
 
 BF = torch.bfloat16

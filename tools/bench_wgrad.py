@@ -3,6 +3,7 @@ LMOD_GEMM_TN4=0) vs the 4-wave TN asm loop without / with deterministic split-K 
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llava-mod_amd"))
+os.environ.setdefault("LMOD_GEMM_ENV_DYNAMIC", "1")      # both arms of a routing switch in one process
 from llavamod import kernels as K
 T = 32768
 def t(fn, n=6):
