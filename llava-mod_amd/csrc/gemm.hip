@@ -2143,7 +2143,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int hx = 0; hx < 2; ++hx) { *(u32x4*)(op + hx * 8) = G[b][pc][hx]; *(u32x4*)(op + p.N + hx * 8) = U[b][pc][hx]; }
       }
     };
+#ifndef G4_SB_DEPTH
+#define G4_SB_DEPTH 2                // [gate | up] batches in flight (round 6 experiment, bit-identical): 1 / 2 / 3 measure THE SAME (profiles/
+#endif                               //   r06_epilogue_ab.md: 0.898 / 0.90 / 0.897 ms dense) — this epilogue is not a chain of memory round trips.
+                                     //   Its ISA is 3454 VALU instructions per lane and tile, 512 of them quarter-rate (v_exp, v_rcp): ~11 us of
+                                     //   issue time beside a 49 us K loop, plus the [gate | up] read and [dgate | dup] write of 512 KiB per tile.
+#if G4_SB_DEPTH == 3
+    ld(0); ld(1); ld(2); cmp(0); pin(0); st(0); ld(3); cmp(1); pin(1); st(1); cmp(2); pin(2); st(2); cmp(3); st(3);
+#elif G4_SB_DEPTH == 2
+    ld(0); ld(1); cmp(0); pin(0); st(0); ld(2); cmp(1); pin(1); st(1); ld(3); cmp(2); pin(2); st(2); cmp(3); st(3);
+#else
     ld(0); cmp(0); pin(0); ld(1); st(0); cmp(1); pin(1); ld(2); st(1); cmp(2); pin(2); ld(3); st(2); cmp(3); st(3);
+#endif
     if (Mz4 != Mv) {                                 // rows Mv .. roundup8(Mv)-1 are zeroed (a k_valid wgrad reads whole 8-row chunks)
 #pragma unroll
       for (int pc = 0; pc < 16; ++pc) {
@@ -2207,10 +2218,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int h = 0; h < 2; ++h) if (colof(gq) + h * H2 + 8 <= p.N) st_c(cp + h * H2, RR[b][pc][h]);
       }
     };
+#ifndef G4_RES_DEPTH
+#define G4_RES_DEPTH 4               // residual batches in flight (round 6; 1 = the round-4 order: one 16 KiB batch at a time).  Bit-identical; measured
+#endif                               //   +1.5 ... 2 % at [32768 x 2048 x 2048] and [32768 x 4096 x 4096], level at K >= 5504 (profiles/r06_epilogue_ab.md)
+#if G4_RES_DEPTH > 1
+#pragma unroll
+    for (int b = 0; b < G4_RES_DEPTH; ++b) ld(b);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { cmp(b); pin(b); st(b); if (b + G4_RES_DEPTH < 8) ld(b + G4_RES_DEPTH); }
+#else
     ld(0); cmp(0); pin(0);
 #pragma unroll
     for (int b = 1; b < 8; ++b) { ld(b); st(b - 1); cmp(b); pin(b); }
     st(7);
+#endif
   } else if constexpr (MODE == 6) {
     // fp32 C += acc (no bias / act / split; C and ldc 16-byte aligned, N % 16 == 0 not required: whole 4-column groups), four
     // batches of 4 pieces as above
@@ -2731,6 +2752,7 @@ struct GemmRouting {
   int min_rounds;       // LMOD_GEMM_PERSIST_ROUNDS: from this many rounds of the CUs up (4)
   int grouped;          // LMOD_GEMM_PERSIST_GROUPED: 0 none, 1 fused SwiGLU forward (default), 2 plain grouped launches too
   int sb4;              // LMOD_GEMM_SB4: dense fused SwiGLU backward on the persistent 4-wave kernel (1)
+  int sb4g;             // LMOD_GEMM_SB4G: GROUPED (MoE) fused SwiGLU backward on the persistent grouped walk of the 4-wave kernel (round 6; 1)
   int kv4;              // LMOD_GEMM_KV4: k_valid batches (MoE expert weight gradients) on the 4-wave kernel (1)
   int tn4;              // LMOD_GEMM_TN4: fp32-accumulate TN launches on gemm4t_kernel (1)
 };
@@ -2741,6 +2763,7 @@ static GemmRouting read_gemm_routing() {
   r.min_rounds = geti("LMOD_GEMM_PERSIST_ROUNDS", 4);
   r.grouped = geti("LMOD_GEMM_PERSIST_GROUPED", 1);
   r.sb4 = geti("LMOD_GEMM_SB4", 1) != 0;
+  r.sb4g = geti("LMOD_GEMM_SB4G", 1) != 0;
   r.kv4 = geti("LMOD_GEMM_KV4", 1) != 0;
   r.tn4 = geti("LMOD_GEMM_TN4", 1) != 0;
   return r;
@@ -2768,14 +2791,14 @@ static bool gemm_persist(const GemmP& p, long long nwg) {
 // the fused SwiGLU forward only; LMOD_GEMM_PERSIST_GROUPED=2 adds the plain grouped launches, 0 keeps one tile per workgroup.
 static bool gemm_persist_grouped(const GemmP& p, long long nwg, const int mode) {
   const GemmRouting r = gemm_routing();
-  const int on = r.persist && (mode == 1 ? r.grouped >= 1 : r.grouped >= 2);
+  const int on = r.persist && (mode == 1 ? r.grouped >= 1 : mode == 4 ? r.sb4g : r.grouped >= 2);
   return on && G4_ASM && p.m_valid && !p.k_valid && p.splitk <= 1 && p.batch >= 1 && p.batch <= GEMM_MAX_GROUPS &&
          nwg >= (long long)r.min_rounds * gemm_cus() && (p.K & 63) == 0 && p.K >= 256;
 }
 template <int MODE>
 static void launch_4(const GemmP& p0, long long nwg, hipStream_t stream) {
   static bool a = false, ap = false, apg = false;
-  if constexpr (MODE == 1 || MODE == 7) {
+  if constexpr (MODE == 1 || MODE == 7 || MODE == 4) {
     if (gemm_persist_grouped(p0, nwg, MODE)) {
       allow_lds(gemm4_kernel<MODE, true, true>, 2 * G4_STAGE, apg);
       hipLaunchKernelGGL((gemm4_kernel<MODE, true, true>), dim3((unsigned)gemm_cus()), dim3(256), 2 * G4_STAGE, stream, p0);
@@ -2807,7 +2830,11 @@ static void launch_256(const GemmP& p, long long nwg, hipStream_t stream) {
   } else if (w == 4) {
     allow_lds(gemm4_kernel<MODE>, 2 * G4_STAGE, a4);
     hipLaunchKernelGGL(gemm4_kernel<MODE>, dim3((unsigned)nwg), dim3(256), 2 * G4_STAGE, stream, p);
-  } else if (MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3 && (w == 44 || (w == 0 && gemm_sb4() && gemm_persist(p, nwg)))) {
+  } else if (MODE == 0 && p.splitk <= 1 && !p.k_valid && p.act == 3 &&
+             (w == 44 || (w == 0 && gemm_sb4() && gemm_persist(p, nwg)) || (w == 0 && gemm_persist_grouped(p, nwg, 4)))) {
+    // (round 6) GROUPED launches (MoE experts: m_valid live rows per slab) take the persistent grouped walk of the same instantiation:
+    // live tiles only, the next tile's operands in flight under this tile's [gate | up] loads and [dgate | dup] stores (LMOD_GEMM_SB4G=0:
+    // the 8-wave instantiation, one tile per workgroup)
     // fused SwiGLU backward: launches that take the PERSISTENT 4-wave form (dense layers: no m_valid, >= 4 rounds of the CUs) run
     // 2.8 - 3.8 % faster there, bit-identical (round 5 routing; tools/probe/swiglu_bwd_variants.py; LMOD_GEMM_SB4=0 is the A/B arm);
     // grouped (MoE) launches keep the 8-wave instantiation with its two-batch epilogue (one tile per workgroup: 1124 vs 1177 us)

@@ -780,6 +780,37 @@ def test_attn_bwd_ds_spill_form_matches_the_two_kernel_form(monkeypatch, B, S, n
         close(one[:, :nh * hd].reshape(B, S, nh, hd), torch.nan_to_num(qf.grad), "attn dQ (dS spill)", rtol=2 ** -5, afrac=2 ** -6)
 
 
+@pytest.mark.parametrize("rows", [[3000, 0, 1793, 257], [3000] * 4, [5, 0, 0, 300], [256] * 16])
+def test_grouped_swiglu_backward_on_the_persistent_walk_is_bit_identical(rows, monkeypatch):
+    """Round 6: the GROUPED fused SwiGLU backward (MoE experts' down-projection dgrad with dgate / dup in the epilogue) on the persistent
+    grouped walk of the four-wave kernel (LMOD_GEMM_SB4G, default on) against the 8-wave one-tile-per-workgroup instantiation: bit-identical
+    [dgate | dup], rows up to the next multiple of 8 zeroed, dead rows untouched; ragged counts with an empty expert and a 1-row tile tail,
+    full slabs, almost everything dead, 16 experts of one row tile."""
+    E, C = len(rows), 3000 if max(rows) > 256 else 256
+    H, I = 512, 1280
+    dy, wt, gu = rnd(E, C, H, seed=70), rnd(E, I, H, seed=71), rnd(E, C, 2 * I, seed=72)
+    mv = torch.tensor(rows, device=DEV, dtype=torch.int32)
+    monkeypatch.setenv("LMOD_GEMM_PERSIST", "1")
+    monkeypatch.setenv("LMOD_GEMM_PERSIST_ROUNDS", "0")
+
+    def run():
+        out = torch.full((E, C, 2 * I), 7.0, device=DEV, dtype=BF)
+        K.gemm_swiglu_bwd(dy, wt, gu, out=out, m_valid=mv, K=H)
+        return out
+    monkeypatch.setenv("LMOD_GEMM_SB4G", "1")
+    a = run()
+    monkeypatch.setenv("LMOD_GEMM_SB4G", "0")
+    b = run()
+    assert torch.equal(a, b)
+    for e in range(E):
+        n = rows[e]; n8 = min((n + 7) // 8 * 8, C)
+        assert n8 == n or a[e, n:n8].abs().max().item() == 0
+        assert n8 == C or (a[e, n8:] == 7.0).all(), "dead rows must not be written"
+        if n:
+            ref = K.gemm_swiglu_bwd(dy[e, :n].contiguous(), wt[e], gu[e, :n].contiguous(), K=H)
+            assert torch.equal(a[e, :n], ref), f"expert {e}"
+
+
 @pytest.mark.parametrize("T,nh,nkv,Kd", [(1000, 4, 4, 512), (777, 6, 2, 256), (2048, 16, 16, 2048)])
 def test_fused_qkv_rope_gemm_is_bit_identical_to_gemm_plus_rope(T, nh, nkv, Kd):
     """lmod_gemm_qkv_rope_bf16 (rotary embedding in the QKV GEMM's epilogue: rounded acc + bias swapped between neighbouring
