@@ -388,7 +388,8 @@ def _mem_total_gb():
     return 0.0
 
 
-def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None, stage="mimic", twin_device="cuda"):
+def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None, stage="mimic", twin_device="cuda", dpo_pairs=1,
+                 forced_arm=False):
     """The oracle (fp32 PyTorch restatement of the reference, oracle/) timed on this box's host cores on ONE sample of the
     same workload (config 2, B=1, S=2048): teacher forward + student forward/backward + losses (no optimizer step).
 
@@ -519,7 +520,7 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                 dp_ = _to_dev(pair, dev)
                 seqs = {"chosen": dict(input_ids=dp_["chosen_input_ids"], labels=dp_["chosen_labels"], attention_mask=dp_["chosen_attention_mask"], images=dp_["images"]),
                         "rejected": dict(input_ids=dp_["rejected_input_ids"], labels=dp_["rejected_labels"], attention_mask=dp_["rejected_attention_mask"], images=dp_["images"])}
-                tok = {}
+                tok, raw_err = {}, {}
                 for m in moes:
                     m.deterministic, m.gate_noise = True, None
                 with torch.no_grad():
@@ -527,9 +528,12 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                         for side, b_ in seqs.items():
                             o_ = mdl(**b_)
                             r_ = tok_ref[f"{who}/{side}"]
-                            e = {"gpu_bf16": _token_stats(_token_logps(o_.logits, o_.labels), r_)}
+                            g_ = _token_logps(o_.logits, o_.labels)
+                            e = {"gpu_bf16": _token_stats(g_, r_)}
+                            raw_err[f"{who}/{side}"] = {"gpu_bf16": [(g_ - r_).double()]}
                             for kname, tv in tok_tw.get(f"{who}/{side}", {}).items():
                                 e[kname] = _token_stats(tv, r_)
+                                raw_err[f"{who}/{side}"].setdefault(kname, []).append((tv - r_).double())
                             tw_rms = max([v["rms"] for kk, v in e.items() if kk != "gpu_bf16"] or [0.0])
                             e["gpu_rms_over_twin_rms"] = round(e["gpu_bf16"]["rms"] / tw_rms, 3) if tw_rms > 0 else None
                             tok[f"{who}/{side}"] = e
@@ -540,6 +544,8 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                 out["token_logp_note"] = ("per labelled token: log p(label) of the GPU product path (full-logits forward of the same models) and of the oracle's "
                                           "bf16 twin minus the fp32 oracle's; rms / bias over the sequence's 512 tokens, sum_dev = the deviation of the "
                                           "sequence log-probability, rms_x_sqrt_n = what a sum of independent errors of that rms would deviate by")
+                if dpo_pairs > 1:
+                    out["token_logp_pooled"] = dpo_token_logp_more_pairs(student, teacher, o_student, o_teacher, sc, tc, vc, dpo_pairs, twin_device, raw_err)
             except Exception as e:
                 out["token_logp_vs_fp32"] = {"error": repr(e)[:300]}
         return out
@@ -556,15 +562,21 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
         old = [(m.deterministic, m.gate_noise) for m in moes]
         for m in moes:
             m.deterministic, m.gate_noise = True, None
-        grad_cmp = None
+        grad_cmp, gpu_picks, hg_keep = None, [], {}
         if gb is not None:
             # FREE-RUNNING full-depth gradients too: the GPU step's backward (both sides route on their own, no forced picks)
             # against the oracle's, relative Frobenius error of a sample of trainable tensors
             from oracle.llava import hip_to_oracle_key
             gb.flat.zero_()
+            gpu_picks, pick_hooks = [], []
+            for m in moes:                                    # the product path's own expert picks, layer by layer (one forward)
+                pick_hooks.append(m.register_forward_hook(
+                    lambda mod, a, o, dst=gpu_picks: dst.append((mod.last_state.idx1.detach().cpu(), mod.last_state.idx2.detach().cpu()))))
             loss_g, outs = trainer.compute_loss(student, b, return_outputs=True)
             loss_g.backward()
             torch.cuda.synchronize()
+            for h_ in pick_hooks:
+                h_.remove()
             ograd = {n: p.grad for n, p in o_student.named_parameters() if p.grad is not None}
             want = ("model.mm_projector.image_spatial_proj.0.weight", "model.mm_projector.image_spatial_proj.2.weight",
                     "model.layers.23.mlp.down_proj.weight", "model.layers.1.mlp.gate_proj.weight",
@@ -572,13 +584,14 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
                     "model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.0.up_proj.weight",
                     "model.layers.12.mlp.deepspeed_moe.experts.deepspeed_experts.3.down_proj.weight")
             named = dict(student.named_parameters())
-            grad_cmp = {}
+            grad_cmp, hg_keep = {}, {}
             for n in want:
                 og = ograd.get(hip_to_oracle_key(n))
                 hg = getattr(named.get(n), "main_grad", None)
                 if og is None or hg is None:
                     continue
                 hg = hg.detach().float().cpu()
+                hg_keep[n] = hg                                # (the GPU buffer is zeroed below; the forced-picks arm compares against these)
                 grad_cmp[n] = round(float((hg - og).norm() / og.norm().clamp_min(1e-30)), 5)
             gb.flat.zero_()
         else:
@@ -621,6 +634,34 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
             g, c = float(outs[k].detach()), float(logs[k].detach())
             loss_delta[k] = _floor_entry(g, c, float(tw_logs["forced"][k]) if "forced" in tw_logs else None,
                                          float(tw_logs["free"][k]) if "free" in tw_logs else None)
+        if grad_cmp and forced_arm and len(gpu_picks) == len(_oracle_moes(o_student)):
+            # the arm that isolates ARITHMETIC from ROUTING at full depth — the fp32 oracle run again with the GPU
+            # product path's expert picks forced into every MoE layer (a second host step), its gradients against the GPU's: what is
+            # left is rounding alone, to be held against the twin's forced-picks floor
+            try:
+                t0 = time.time()
+                for m, pk_ in zip(_oracle_moes(o_student), gpu_picks):
+                    m.forced = pk_
+                o_student.zero_grad(set_to_none=True)
+                _, logs_f, _, _ = mimic_step(o_student, o_teacher, cb, loss_type="kd_lm")
+                fgrad = {n: p.grad for n, p in o_student.named_parameters() if p.grad is not None}
+                forced_cmp = {}
+                for n in grad_cmp:
+                    og = fgrad.get(hip_to_oracle_key(n))
+                    if og is not None and hg_keep.get(n) is not None:
+                        forced_cmp[n] = round(float((hg_keep[n] - og).norm() / og.norm().clamp_min(1e-30)), 5)
+                loss_delta["grad_rel_frobenius_gpu_picks_forced_into_fp32_oracle"] = forced_cmp
+                fl = tw_grads.get("forced") or {}
+                loss_delta["grad_gpu_picks_forced_within_2x_twin_forced_floor"] = {n: bool(v <= 2.0 * fl[n]) for n, v in forced_cmp.items() if n in fl}
+                loss_delta["loss_gpu_picks_forced"] = {k: {"gpu_bf16": round(float(outs[k].detach()), 6), "cpu_fp32_gpu_picks": round(float(logs_f[k].detach()), 6),
+                                                           "rel": round(abs(float(outs[k].detach()) - float(logs_f[k].detach())) / max(abs(float(logs_f[k].detach())), 1e-30), 6)}
+                                                       for k in ("loss", "loss/align", "loss/lm", "loss/moe_balance")}
+                loss_delta["forced_arm_note"] = f"second fp32 oracle step on the host with the GPU's picks forced: {time.time() - t0:.1f} s"
+            except Exception as e:
+                loss_delta["forced_arm_note"] = "forced arm failed: " + repr(e)[:300]
+            finally:
+                for m in _oracle_moes(o_student):
+                    m.forced = None
         if grad_cmp:
             loss_delta["grad_rel_frobenius_free_running"] = grad_cmp
             if tw_grads:
@@ -645,6 +686,90 @@ def cpu_baseline(student=None, teacher=None, trainer=None, mode="auto", gb=None,
     except Exception as e:
         out["config1"] = {"error": repr(e)[:200]}
     return out
+
+
+def dpo_token_logp_more_pairs(student, teacher, o_student, o_teacher, sc, tc, vc, k_pairs, twin_device, raw_err):
+    """the per-token log-probability statistic over k >= 4 INDEPENDENT chosen / rejected pairs at full depth.  The
+    first pair's errors come from the caller; every further pair costs four forward passes of the fp32 oracle on the host (no backward),
+    the same four through the GPU product path and through the oracle's bf16 twin (free-running, and with the fp32 run's expert picks
+    forced).  Pooled per sequence kind (policy / reference x chosen / rejected): n tokens, mean error +- sigma / sqrt(n), the mean in
+    units of that standard error, and whether |mean| <= 3 sigma / sqrt(n) — the quantity a sequence log-probability (a sum over tokens)
+    and with it every reward inherits — for the product and for the twin."""
+    dev = next(student.parameters()).device
+    moes = student.moe_layers()
+    old = [(m.deterministic, m.gate_noise) for m in moes]
+    tw_s = tw_t = None
+    note = []
+    t0 = time.time()
+    try:
+        if twin_device != "off":
+            tdev = torch.device(twin_device if twin_device == "cpu" else dev)
+            tw_s, tw_t = cpu_baseline_twin(sc, vc, True, student, tdev), cpu_baseline_twin(tc, vc, False, teacher, tdev)
+            tw_s.train(); tw_t.eval(); tw_s.set_gate_noise(None)
+        o_student.train(); o_teacher.eval(); o_student.set_gate_noise(None)
+        for m in moes:
+            m.deterministic, m.gate_noise = True, None
+        for k in range(1, k_pairs):
+            ch, rj = synthetic_batch(1, 3 + 101 * k), synthetic_batch(1, 5003 + 101 * k)
+            seqs = {"chosen": dict(input_ids=ch["input_ids"], labels=ch["labels"], attention_mask=ch["attention_mask"], images=ch["images"]),
+                    "rejected": dict(input_ids=rj["input_ids"], labels=rj["labels"], attention_mask=rj["attention_mask"], images=ch["images"])}
+            for m in _oracle_moes(o_student):
+                m.forced = None
+            hist, handles = _record_picks(o_student)
+            ref = {}
+            with torch.no_grad():
+                for side, b_ in seqs.items():
+                    fb = dict(b_, images=b_["images"].float())
+                    o_ = o_student(**fb); ref[f"policy/{side}"] = _token_logps(o_.logits, o_.labels); del o_
+                    o_ = o_teacher(**fb); ref[f"reference/{side}"] = _token_logps(o_.logits, o_.labels); del o_
+            for h in handles:
+                h.remove()
+            with torch.no_grad():
+                for who, mdl in (("policy", student), ("reference", teacher)):
+                    for side, b_ in seqs.items():
+                        o_ = mdl(**_to_dev(b_, dev))
+                        raw_err[f"{who}/{side}"]["gpu_bf16"].append((_token_logps(o_.logits, o_.labels) - ref[f"{who}/{side}"]).double())
+                        del o_
+                if tw_s is not None:
+                    for side, b_ in seqs.items():
+                        tb = _to_dev(b_, tdev)
+                        with torch.device(tdev):
+                            o_ = tw_t(**tb)
+                            raw_err[f"reference/{side}"].setdefault("twin", []).append((_token_logps(o_.logits, o_.labels) - ref[f"reference/{side}"]).double())
+                            del o_
+                    for tag, forced in (("twin_forced", True), ("twin_free", False)):
+                        # the student ran chosen then rejected: call c of every layer's history belongs to sequence c
+                        for ci, (side, b_) in enumerate(seqs.items()):
+                            for m, h in zip(_oracle_moes(tw_s), hist):
+                                m.forced = [(h[ci][0].to(tdev), h[ci][1].to(tdev))] if forced else None
+                            with torch.device(tdev):
+                                o_ = tw_s(**_to_dev(b_, tdev))
+                            raw_err[f"policy/{side}"].setdefault(tag, []).append((_token_logps(o_.logits, o_.labels) - ref[f"policy/{side}"]).double())
+                            del o_
+            note.append(round(time.time() - t0, 1))
+    finally:
+        for m, (d, n) in zip(moes, old):
+            m.deterministic, m.gate_noise = d, n
+        for m in _oracle_moes(o_student):
+            m.forced = None
+        del tw_s, tw_t
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+    pooled = {}
+    for name, arms in raw_err.items():
+        pooled[name] = {}
+        for arm, parts in arms.items():
+            e = torch.cat(parts)
+            n, mean, sd = e.numel(), float(e.mean()), float(e.std())
+            se = sd / n ** 0.5
+            pooled[name][arm] = {"pairs": len(parts), "n": n, "mean": round(mean, 6), "sigma": round(sd, 6), "stderr": round(se, 6),
+                                 "mean_in_stderr": round(abs(mean) / se, 2) if se > 0 else None, "within_3_stderr": bool(abs(mean) <= 3.0 * se),
+                                 "rms": round(float(e.pow(2).mean().sqrt()), 6),
+                                 "sequence_sum_devs": [round(float(p_.sum()), 4) for p_ in parts]}
+    pooled["note"] = (f"{k_pairs} independent chosen / rejected pairs, 512 labelled tokens per sequence; pairs 2.. are forward-only on the fp32 oracle "
+                      f"(cumulative seconds after each: {note}); error = log p(label) minus the fp32 oracle's; a reward is 0.1 x a difference of two "
+                      "sequence sums of such errors, so a mean inside 3 standard errors on every sequence kind is the statement that no arm carries a bias")
+    return pooled
 
 
 def cpu_baseline_twin(cfg, vcfg, moe, product_model, device):
@@ -826,6 +951,12 @@ def main():
     ap.add_argument("--twin-device", default="cuda", choices=["cuda", "cpu", "off"],
                     help="where the oracle's full-depth bf16 twin (the noise floor printed beside every loss_delta) executes: eager "
                          "torch on the GPU (seconds), the host cores (minutes), or not at all")
+    ap.add_argument("--cpu-forced-arm", action="store_true",
+                    help="full-depth cpu_baseline (mimic): a second fp32 oracle step on the host with the GPU's expert picks forced, so that the "
+                         "gradient comparison isolates arithmetic from routing (+ ~3 min of host time; off in the default run)")
+    ap.add_argument("--dpo-pairs", type=int, default=1,
+                    help="--stage dpo, full-depth cpu_baseline: pool the per-token log-prob statistic over this many independent pairs "
+                         "(pairs beyond the first are forward-only on the fp32 oracle: ~2 min of host time each)")
     ap.add_argument("--optimizer-overlap", action="store_true",
                     help="just-in-time AdamW on a second stream (bit-identical; measured 0.3 %% slower than serial, off by default)")
     ap.add_argument("--separate-towers", action="store_true", help="different random CLIP towers: both are run (no feature sharing)")
@@ -1053,7 +1184,8 @@ def main():
                 out["extra"] = {"config4_pairs_per_s": {"error": repr(e)[:300]}}
         if world == 1 and not args.no_cpu_baseline and not args.ragged:
             try:
-                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer, args.cpu_baseline, gb=gb, stage=args.stage, twin_device=args.twin_device)
+                out["cpu_baseline"] = cpu_baseline(student, teacher, trainer, args.cpu_baseline, gb=gb, stage=args.stage, twin_device=args.twin_device,
+                                                   dpo_pairs=args.dpo_pairs, forced_arm=args.cpu_forced_arm)
             except Exception as e:                              # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         if want_extras:

@@ -1,6 +1,6 @@
 """Turn rocprofv3 outputs under gpurun_out/<run>/ into the markdown summaries committed under profiles/.
 usage: python tools/profile_md.py gpurun_out/final profiles/r01_final"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 
 src, dst = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("", "")
 TAG = os.path.basename(dst).replace("_", " ")
@@ -50,10 +50,14 @@ def stats_md():
     blocks = (gm // 256) * (12288 // 256)
     # (round 3: plain bf16 launches run on the 4-wave kernel, 256 threads per workgroup; older builds / LMOD_GEMM_WAVES=8: 512)
     rl = line["roofline"]
-    if any("gemm4_kernel<7, true" in r["Kernel_Name"] for r in trace):      # (round 5: a third template flag follows — `<7, true, false>`)
+    # round 6: WHICH kernel bench.py times live follows the committed kernel summary (bench.roofline_recipe): the instantiation number is
+    # in the label (`gemm4_kernel<1> (fused SwiGLU forward ...`), its persistent form is `gemm4_kernel<N, true, false>` in the trace
+    mnum = re.match(r"gemm4_kernel<(\d+)>", rl.get("kernel", ""))
+    dnum = mnum.group(1) if mnum else "7"
+    if any(f"gemm4_kernel<{dnum}, true, false" in r["Kernel_Name"] for r in trace):
         # round 4: the teacher-QKV launch (24 rounds of the CUs) runs on the PERSISTENT instantiation, whose grid is one workgroup
         # per CU whatever the shape: the bench's own launches are told apart by their duration (+-12 % of the live figure)
-        dom = "gemm4_kernel<7, true"
+        dom = f"gemm4_kernel<{dnum}, true, false"
         # (with the persistent form taken from 4 rounds up several shapes of the step run on this instantiation with the same grid
         # and similar durations: the bench's own launches are the one place where the kernel is dispatched back to back, so they
         # are the LONGEST RUN of consecutive dispatches of it in start order)
@@ -74,28 +78,27 @@ def stats_md():
         tpw = 256 if dom.startswith("gemm4") else 512
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
              if dom in r["Kernel_Name"] and int(r["Grid_Size_X"]) // tpw == blocks]
+    shape_txt = rl.get("kernel", "").split("@")[-1].strip() if "@" in rl.get("kernel", "") else f"teacher QKV [{gm} x 12288 x 4096]"
     out += ["", "## Dominant kernel cross-check", "",
-            f"`{dom}{'>' if dom.endswith('0') else ('...>' if dom.endswith('true') else '')}` launches with the teacher-QKV grid ({blocks} workgroups = [{gm} x 12288 x 4096]): {len(d)} in the "
-            f"trace (the launches bench.py times with HIP events; the models' own QKV projections run on the fused QKV + RoPE instantiation), average {sum(d) / len(d):.1f} us, "
+            f"`{dom}{'>' if not dom.endswith('0') else '>'}`: the longest run of back-to-back dispatches in the trace = the launches bench.py times with HIP events "
+            f"({shape_txt}): {len(d)} launches (2 untimed + 10 timed), average {sum(d) / len(d):.1f} us, "
             f"min {min(d):.1f}, max {max(d):.1f}.  bench.py's live HIP-event figure in the same run: {rl['launch_ms'] * 1e3:.1f} us "
-            f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak)."]
+            f"per launch = {rl['achieved']} TFLOP/s ({rl['frac'] * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak).  {rl.get('dominant_by', '')}"]
     by = collections.defaultdict(lambda: [0, 0.0])
     for r in trace:
         if "gemm_256_kernel" in r["Kernel_Name"] or "gemm4_kernel" in r["Kernel_Name"]:
             k = (r["Kernel_Name"][5:30].split("(")[0], int(r["Grid_Size_X"]) // (256 if "gemm4_kernel" in r["Kernel_Name"] else 512))
             by[k][0] += 1; by[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in trace:
-        if "gemm4_kernel<7" in r["Kernel_Name"]:
-            kk = "persistent" if "gemm4_kernel<7, true" in r["Kernel_Name"] else "one tile per workgroup"
-            agg[kk][0] += 1; agg[kk][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    if agg:
-        ins = rl.get("in_step") or {}
-        out += ["", "## The dominant kernel inside the step", "",
-                "`gemm4_kernel<7>` launches in this trace: " + "; ".join(f"{k}: {n} launches, {ms:.1f} ms" for k, (n, ms) in agg.items()) +
-                f".  bench.py's own in-step aggregate (one extra step, HIP events around every `lmod_gemm_bf16_nt` launch routed to this kernel): "
-                f"{ins.get('launches')} launches, {ins.get('ms')} ms, **{ins.get('achieved')} TFLOP/s = {100 * (ins.get('frac') or 0):.1f} % of peak** "
-                f"(sum of flops / sum of durations)."]
+    ins = rl.get("in_step") or {}
+    fams = ins.get("families") or {}
+    if fams:
+        out += ["", "## The MFMA kernels inside the step (bench.py's in-step aggregate: one extra step, HIP events around every launch)", "",
+                "| family (entry point) | launches | ms per step | TFLOP/s (launches with a host-known flop count) | of 2.5 PF |", "|---|---|---|---|---|"]
+        for k, v in fams.items():
+            out.append(f"| {k} | {v['launches']} | {v['ms']} | {v['achieved']} | {v['frac']} |")
+        out += ["", "Top shapes per family:", ""]
+        for k, v in fams.items():
+            out.append(f"* {k}: " + "; ".join(f"`{sk}` x{sv['launches']} {sv['ms']} ms" + (f" {sv['tflops']} TF" if sv.get('tflops') else "") for sk, sv in v["by_shape"].items()))
     out += ["", "## 256-tile GEMM launches by grid size (workgroups; 256 CUs => `waves` rounds)", "",
             "| kernel | workgroups | rounds | calls | total ms |", "|---|---|---|---|---|"]
     for (k, nb), (n, ms) in sorted(by.items(), key=lambda t: -t[1][1])[:16]:
@@ -123,14 +126,16 @@ def pmc_md():
            "Per-dispatch averages.  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles; "
            "`SQ_VALU_MFMA_BUSY_CYCLES` counts cycles summed over the 1024 SIMDs; `GRBM_GUI_ACTIVE` is summed over the 8 XCDs.", ""]
     g = pmc("gemm_sq"); f = pmc("gemm_fetch"); w = pmc("gemm_write")
-    k = next(x for x in g if "gemm4_kernel" in x or "gemm_256" in x)      # whichever kernel the plain bf16 GEMM launch runs on
+    k = next(x for x in g if "gemm4_kernel" in x or "gemm_256" in x)      # whichever kernel tools/gemm_one.py launched
     kname = k.replace("void ", "").split("(")[0]
     c, us = g[k]
     fetch_kb, write_kb = f[k][0]["FETCH_SIZE"], w[k][0]["WRITE_SIZE"]
-    M, N, Kd = 32768, 12288, 4096
-    algo_nt = gemm_algorithmic_bytes(M, N, Kd)
+    meta = json.load(open(f"{src}/gemm_one_meta.json")) if os.path.exists(f"{src}/gemm_one_meta.json") else {"kind": "nt", "shape": [32768, 12288, 4096]}
+    M, N, Kd = meta["shape"]
+    out_cols = meta.get("output_cols", N)                 # fused SwiGLU forward: the GEMM is N = 2I wide, the result I
+    algo_nt = (M * Kd + N * Kd + M * out_cols) * 2
     clk = c["GRBM_GUI_ACTIVE"] / 8 / us / 1e3
-    out += [f"## `{kname}` at the teacher QKV shape [{M} x {N} x {Kd}] (`python tools/gemm_one.py`)", "",
+    out += [f"## `{kname}` at {meta.get('what', 'the teacher QKV shape')} [{M} x {N} x {Kd}] (`{meta.get('cmd', 'python tools/gemm_one.py')}`)", "",
             f"* duration under the counter passes: {us:.0f} us ({2.0 * M * N * Kd / us / 1e6:.0f} TFLOP/s; counter collection and its lower "
             f"clock cost ~10 % against the un-profiled {2.0 * M * N * Kd / 1e12:.2f} TFLOP launch in bench.py)",
             f"* effective clock: GRBM_GUI_ACTIVE / 8 / duration = **{clk:.2f} GHz** (peak 2.4): the chip is power-limited under this kernel",
@@ -138,7 +143,7 @@ def pmc_md():
             f"* LDS: SQ_LDS_BANK_CONFLICT = {c['SQ_LDS_BANK_CONFLICT']:.0f} (conflict-free swizzle), SQ_LDS_IDX_ACTIVE / 256 CUs = "
             f"{c['SQ_LDS_IDX_ACTIVE'] / 256 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.0f} % of cycles",
             f"* memory side: FETCH_SIZE {fetch_kb / 1e6:.3f} GB x 2 (gfx950 16-byte-lane correction, MI355X_MICROARCH.md §HBM) = "
-            f"**{2 * fetch_kb / 1e6:.2f} GB**, WRITE_SIZE **{write_kb / 1e6:.2f} GB** per launch; algorithmic bytes (A + B + C once) "
+            f"**{2 * fetch_kb / 1e6:.2f} GB**, WRITE_SIZE **{write_kb / 1e6:.2f} GB** per launch; algorithmic bytes (operands + result once) "
             f"{algo_nt / 1e9:.2f} GB => {(2 * fetch_kb * 1e3 + write_kb * 1e3) / algo_nt:.2f}x.  The fetch figure counts every L2 miss at the fabric, Infinity-Cache hits included: an XCD's 32 "
             "concurrent 256x256 tiles form a 4 x 8 rectangle that needs 12 operand panels per K sweep, 24 sweeps per XCD "
             "=> ~4.8 GB by construction; the 256 MB Infinity Cache absorbs the re-reads (B = 0.10 GB stays resident), so this is "
@@ -169,7 +174,7 @@ def pmc_md():
             "clock not yet settled: durations are longer than in the micro-benchmarks)", "",
             "| kernel | us | clock GHz | MFMA busy % | LDS active % of CU cycles | LDS conflict / active | WAIT_ANY / WAVE_CYCLES |", "|---|---|---|---|---|---|---|"]
     for k, (c, us) in a.items():
-        if "attn" not in k or "delta" in k:
+        if ("attn" not in k and "gemm4t_kernel<2" not in k) or "delta" in k:       # (gemm4t_kernel<2>: dQ from the spilled dS, round 6)
             continue
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         out.append(f"| `{k}` | {us:.0f} | {cyc / us / 1e3:.2f} | {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.0f} | "
@@ -180,13 +185,13 @@ def pmc_md():
         out += ["", "Instruction mix per dispatch (millions of wave-instructions; ACTIVE / WAIT in millions of quad-cycles):", "",
                 "| kernel | MFMA | VALU | LDS | SALU | VMEM rd | VALU per MFMA | ACTIVE_INST_VALU | ACTIVE_INST_LDS | WAIT_INST_LDS |", "|---|---|---|---|---|---|---|---|---|---|"]
         for k, (c, us) in ai.items():
-            if "attn" not in k or "delta" in k:
+            if ("attn" not in k and "gemm4t_kernel<2" not in k) or "delta" in k:
                 continue
             out.append(f"| `{k}` | {c['SQ_INSTS_MFMA'] / 1e6:.2f} | {c['SQ_INSTS_VALU'] / 1e6:.2f} | {c['SQ_INSTS_LDS'] / 1e6:.2f} | "
                        f"{c['SQ_INSTS_SALU'] / 1e6:.2f} | {c['SQ_INSTS_VMEM_RD'] / 1e6:.2f} | {c['SQ_INSTS_VALU'] / max(1.0, c['SQ_INSTS_MFMA']):.2f} | "
                        f"{c['SQ_ACTIVE_INST_VALU'] / 1e6:.1f} | {c['SQ_ACTIVE_INST_LDS'] / 1e6:.1f} | {c['SQ_WAIT_INST_LDS'] / 1e6:.1f} |")
     open(dst + "_pmc.md", "w").write("\n".join(out) + "\n")
-    json.dump({"kernel": kname, "shape": [M, N, Kd], "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
+    json.dump({"kernel": kname, "shape": [M, N, Kd], **({"output_cols": out_cols} if out_cols != N else {}), "fetch_bytes_corrected": 2 * fetch_kb * 1e3,
                "write_bytes": write_kb * 1e3, "algorithmic_bytes": algo_nt,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md §HBM"},
               open(dst + "_gemm_traffic.json", "w"), indent=1)
@@ -199,6 +204,6 @@ if __name__ == "__main__":
     os.system(f"cp {src}/bench/a_kernel_stats.csv {dst}_bench_kernel_stats.csv")
     if os.path.exists(f"{src}/attn_bench.jsonl"):
         os.system(f"cp {src}/attn_bench.jsonl {dst}_attn_bench.jsonl")
-    for name in ("bench_driver_form.json", "routing.jsonl", "pytest_gpu.txt", "attn_hd64.jsonl"):
+    for name in ("bench_driver_form.json", "routing.jsonl", "pytest_gpu.txt", "attn_hd64.jsonl", "attn_bwd_forms.jsonl"):
         if os.path.exists(f"{src}/{name}"):
             os.system(f"cp {src}/{name} {dst}_{name}")
