@@ -59,3 +59,35 @@ class NativeComm:
         _hip.call("lmod_moe_all_to_all", self._h, _hip.ptr(send), _hip.ptr(recv), ctypes.cast(sr, ctypes.c_void_p),
                   ctypes.cast(rr, ctypes.c_void_p), H)
         return recv
+
+
+# ONE communicator per process over the world: the engine's gradient exchange (side stream) and the expert-parallel
+# all-to-all (compute stream) share it — two RCCL communicators with collectives in flight on different streams is the classic
+# deadlock hazard, one communicator serialises its operations in issue order, which every rank follows identically.
+_SHARED = None
+
+
+def shared_world_comm():
+    """The process's C-ABI communicator over torch.distributed's world, created on first use (COLLECTIVE: rank 0 draws the id, everybody
+    receives it over the existing process group — call it from a point every rank reaches together, e.g. DataParallel.attach)."""
+    global _SHARED
+    if _SHARED is None:
+        import atexit
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = [unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        _SHARED = NativeComm(uid[0], rank, world)
+        atexit.register(close_shared)
+    return _SHARED
+
+
+def close_shared():
+    """Destroy the shared communicator (teardown; idempotent)."""
+    global _SHARED
+    if _SHARED is not None:
+        try:
+            _SHARED.close()
+        finally:
+            _SHARED = None

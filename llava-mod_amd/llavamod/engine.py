@@ -254,6 +254,9 @@ class DataParallel:
             gb.flatten_params()
         if self.enabled and self.grad_dtype == BF16:
             self._gbf = torch.empty(gb.numel, device=gb.flat.device, dtype=BF16)
+        if self.enabled and getattr(self, "native", False) and gb.flat.is_cuda:
+            self.native_comm()                   # eagerly, HERE: every rank attaches at the same point of its set-up (the id broadcast is a
+                                                 # collective); creating it lazily inside an autograd hook is the deadlock hazard ADVICE r05 names
         return self
 
     def owned(self, obj, kind):
@@ -272,10 +275,7 @@ class DataParallel:
         existing process group) and the side stream its collectives are enqueued on."""
         if self._ncomm is None:
             from . import comm
-            uid = [comm.unique_id() if self.rank == 0 else None]
-            if dist.get_world_size() > 1:
-                dist.broadcast_object_list(uid, src=0)
-            self._ncomm = comm.NativeComm(uid[0], self.rank, self.world)
+            self._ncomm = comm.shared_world_comm()       # ONE communicator per process, shared with ops.AllToAllRows
             self._nstream = torch.cuda.Stream()
         return self._ncomm, self._nstream
 

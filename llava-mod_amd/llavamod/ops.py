@@ -785,25 +785,17 @@ class AllToAll(torch.autograd.Function):
         return out, None
 
 
-_NATIVE_WORLD = {}
-
-
 def _native_world_comm(group, x):
-    """LMOD_DP_NATIVE=1 and an expert-parallel group that IS the world (config 5: 8 experts on 8 ranks): the C-ABI communicator of the
-    kernel library (llavamod.comm.NativeComm) instead of torch.distributed; None otherwise."""
+    """LMOD_DP_NATIVE=1 and an expert-parallel group that IS the world (config 5: 8 experts on 8 ranks): the process's ONE C-ABI
+    communicator (llavamod.comm.shared_world_comm — the same object the engine's gradient exchange uses, created in
+    DataParallel.attach) instead of torch.distributed; None otherwise."""
     import torch.distributed as dist
     if os.environ.get("LMOD_DP_NATIVE") != "1" or not x.is_cuda or x.dtype != BF16:
         return None
     if group is not dist.group.WORLD and dist.get_world_size(group) != dist.get_world_size():
         return None
-    key = x.device.index
-    if key not in _NATIVE_WORLD:
-        from . import comm
-        uid = [comm.unique_id() if dist.get_rank() == 0 else None]
-        if dist.get_world_size() > 1:
-            dist.broadcast_object_list(uid, src=0)
-        _NATIVE_WORLD[key] = comm.NativeComm(uid[0], dist.get_rank(), dist.get_world_size())
-    return _NATIVE_WORLD[key]
+    from . import comm
+    return comm.shared_world_comm()
 
 
 class AllToAllRows(torch.autograd.Function):
