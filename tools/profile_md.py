@@ -145,9 +145,9 @@ def pmc_md():
             f"* memory side: FETCH_SIZE {fetch_kb / 1e6:.3f} GB x 2 (gfx950 16-byte-lane correction, MI355X_MICROARCH.md §HBM) = "
             f"**{2 * fetch_kb / 1e6:.2f} GB**, WRITE_SIZE **{write_kb / 1e6:.2f} GB** per launch; algorithmic bytes (operands + result once) "
             f"{algo_nt / 1e9:.2f} GB => {(2 * fetch_kb * 1e3 + write_kb * 1e3) / algo_nt:.2f}x.  The fetch figure counts every L2 miss at the fabric, Infinity-Cache hits included: an XCD's 32 "
-            "concurrent 256x256 tiles form a 4 x 8 rectangle that needs 12 operand panels per K sweep, 24 sweeps per XCD "
-            "=> ~4.8 GB by construction; the 256 MB Infinity Cache absorbs the re-reads (B = 0.10 GB stays resident), so this is "
-            "~2 TB/s of fabric traffic under an MFMA-bound kernel, not HBM over-fetch.",
+            f"concurrent tiles (256 operand rows on each side) form a 4 x 8 rectangle that needs 12 operand panels of 256 x {Kd} bf16 per K sweep; "
+            f"{-(-(M // 256) * (N // 256) // 256)} sweeps of the 8 XCDs => ~{-(-(M // 256) * (N // 256) // 256) * 8 * 12 * 256 * Kd * 2 / 1e9:.1f} GB by construction; the 256 MB "
+            "Infinity Cache absorbs the re-reads, so this is fabric traffic under an MFMA-bound kernel, not HBM over-fetch.",
             "", "| counter | per dispatch |", "|---|---|"]
     out += [f"| {a} | {b:.4g} |" for a, b in sorted(c.items())]
     if glob.glob(f"{src}/wgrad_sq/*counter_collection.csv"):
