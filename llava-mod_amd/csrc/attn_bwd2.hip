@@ -30,6 +30,11 @@
 // Grouped-query launches with too few dK/dV workgroups for the chip are head-split (AttnP::nsplit, lmod_attn_bwd_split in attn.hip): a
 // workgroup takes a PART of its KV head's query heads and stores fp32 partial sums; attn_dkv_reduce_kernel (attn.hip) adds the parts.
 // Work ids go through xcd_work_id (attn_common.h) when the grid's head extent is no multiple of the 8 XCDs.
+//
+// dS spill (round 6; template flag SPILL of the hd-128 dK/dV kernel): the two kernels compute S, dP and the exponentials twice — 7 matmul
+// units for 5 algorithmic ones.  With a workspace the dK/dV kernel also STORES the packed bf16 dS^T it feeds to its dK MFMAs (tile-major
+// 1 KiB blocks, see `ds_store_half`), the dQ kernel is not launched, and dQ = scale * dS K runs as one batched TN GEMM
+// (gemm.hip: gemm4t_kernel<2>).  dK / dV are bit-identical to the two-kernel form.
 #include "attn_common.h"
 #include "attn_acc256.h"
 #include <type_traits>
