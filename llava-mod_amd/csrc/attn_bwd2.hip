@@ -355,11 +355,11 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     asm volatile("" : "+v"(t));
     return (uint32_t)((t & 31) * 32 + ((t >> 5) & 1) * 16);
   };
-  auto ds_store_half = [&](char* base, const int os, const int half) {             // half 0: queries 0-15 of the tile, 1: 16-31
+  auto ds_store_half = [&](char* base, const uint32_t lo, const int os, const int half) {   // half 0: queries 0-15 of the tile, 1: 16-31
     uint32_t* w = &pS[os][4 * half];
     ds_swap(w[0], w[2]);
     ds_swap(w[1], w[3]);
-    __builtin_nontemporal_store((u32x4){w[0], w[1], w[2], w[3]}, (u32x4*)(base + ds_lane() + (os * 2048 + half * 1024)));
+    __builtin_nontemporal_store((u32x4){w[0], w[1], w[2], w[3]}, (u32x4*)(base + lo + (os * 2048 + half * 1024)));
   };
   auto ds_store_zero = [&](char* base) {                                            // a tile this wave skips (wholly above the diagonal)
     const uint32_t lo = ds_lane();
@@ -470,6 +470,8 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
     }
     // ---- dK^T += Xs^T dS
     {
+      uint32_t ds_lo = 0;
+      if constexpr (spill) ds_lo = ds_lane();              // once per tile, live through this phase only
       bf16x8 af[B2_DEPTH + 1];
 #pragma unroll
       for (int st = 0; st < B2_DEPTH; ++st) af[st] = rd_tr(0, st / DT, st % DT);
@@ -485,11 +487,11 @@ __device__ __forceinline__ void bwd2_block(const AttnP& p, char* smem, int ob, i
         if constexpr (DKV && HD == 128) {
           // dS spill: the tk = 0 words (queries 0-15) have fed their last MFMA once the tk = 1 steps begin: one strip behind each of
           // the first two of them; the tk = 1 words follow the phase
-          if constexpr (spill && tk == 1 && dt < 2) ds_store_half(ds_base, dt, 0);
+          if constexpr (spill && tk == 1 && dt < 2) ds_store_half(ds_base, ds_lo, dt, 0);
         }
         B2_SB();
       });
-      if constexpr (spill) { ds_store_half(ds_base, 0, 1); ds_store_half(ds_base, 1, 1); }
+      if constexpr (spill) { ds_store_half(ds_base, ds_lo, 0, 1); ds_store_half(ds_base, ds_lo, 1, 1); }
     }
   };
 
