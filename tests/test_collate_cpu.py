@@ -91,3 +91,20 @@ def test_collators_equal_the_imported_reference_collators():
                 assert v.dtype == torch.bool and torch.equal(v, ref.bool())
             else:
                 assert v.dtype == ref.dtype and torch.equal(v, ref), (tag, k)
+
+
+def test_attention_backward_ds_spill_envelope_is_host_checkable(monkeypatch):
+    """kernels.attn_bwd_ds_fusable mirrors the library's envelope for the 5-matmul backward (csrc/attn.hip): head dim 128, dense layout,
+    whole 256-row blocks, a bounded workspace, and the LMOD_ATTN_DS=0 switch — pure host logic, no device."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-mod_amd"))
+    from llavamod import kernels as K
+    monkeypatch.delenv("LMOD_ATTN_DS", raising=False)
+    assert K.attn_bwd_ds_fusable(16, 2048, 16, 128)
+    assert K.attn_bwd_ds_fusable(4, 8192, 16, 128)                       # exactly 8 GiB of workspace
+    assert not K.attn_bwd_ds_fusable(8, 8192, 16, 128)                   # 16 GiB: over the bound
+    assert not K.attn_bwd_ds_fusable(16, 2048, 14, 64)                   # hd 64 keeps the two-kernel form
+    assert not K.attn_bwd_ds_fusable(16, 2000, 16, 128)                  # not whole 256-row blocks
+    assert not K.attn_bwd_ds_fusable(16, 2048, 16, 128, cu=object())     # packed (varlen) layout
+    monkeypatch.setenv("LMOD_ATTN_DS", "0")
+    assert not K.attn_bwd_ds_fusable(16, 2048, 16, 128)
